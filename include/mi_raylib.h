@@ -1,0 +1,189 @@
+/*
+ * mi_raylib.h — C ABI of the MI355X (gfx950) ray/path-trace hot path.
+ *
+ * This is the drop-in boundary for the device renderer of markp-gc/ipu_ray_lib:
+ * what the reference reaches through `IpuScene` + `ipu_utils::GraphManager().run()`
+ * (reference include/IpuScene.hpp:33-56, caller trace.cpp:270-336) is reached here
+ * through five plain-C entry points. Plain pointers and sizes only; no C++ types,
+ * no torch types, no exceptions cross this boundary. Every function returns an
+ * int status (MI_OK == 0) and leaves a message retrievable with mi_last_error().
+ *
+ * POD layouts are those of the reference (probe sizes in SURVEY.md §8a):
+ *   mi_trace_result == embree_utils::TraceResult   (84 B, include/embree_utils/geometry.hpp:253-259)
+ *   mi_hit_record   == embree_utils::HitRecord     (64 B, geometry.hpp:226-251)
+ *   mi_ray          == embree_utils::Ray           (32 B, geometry.hpp:212-224)
+ *   mi_bvh_node     == CompactBVH2Node             (24 B, include/CompactBVH2Node.hpp:52-85)
+ *   mi_material     == Material                    (36 B, include/Material.hpp:8-35)
+ *   mi_mesh_info    == MeshInfo                    (16 B, include/Mesh.hpp:15-20)
+ *   mi_geom_ref     == GeomRef                     (4 B,  include/Scene.hpp:29-34)
+ * Spheres and discs cross the boundary as vptr-free PODs (the reference's host
+ * Sphere/Disc objects carry vtable pointers, include/Primitives.hpp:36-82).
+ */
+#ifndef MI_RAYLIB_H
+#define MI_RAYLIB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------- */
+enum {
+  MI_OK = 0,
+  MI_ERR_INVALID_ARG = 1,   /* null pointer, bad size, inconsistent scene arrays */
+  MI_ERR_DEVICE = 2,        /* HIP runtime error (message in mi_last_error)      */
+  MI_ERR_NO_NIF = 3,        /* NIF entry point used before weights were loaded   */
+  MI_ERR_IO = 4             /* file could not be read / parsed                   */
+};
+
+/* ---- POD types (layout == reference) ------------------------------------ */
+typedef struct { float x, y, z; } mi_vec3;                      /* Vec3fa, 12 B, align 4 */
+
+typedef struct {
+  mi_vec3 origin; float t_min; mi_vec3 direction; float t_max;
+} mi_ray;                                                        /* 32 B */
+
+typedef struct {
+  mi_ray r;
+  uint32_t prim_id;          /* 0xFFFFFFFF = invalid */
+  mi_vec3 normal;
+  mi_vec3 throughput;
+  uint16_t geom_id;          /* 0xFFFF = invalid */
+  uint16_t flags;            /* MI_FLAG_ERROR | MI_FLAG_ESCAPED */
+} mi_hit_record;                                                 /* 64 B */
+
+typedef struct {
+  mi_vec3 rgb;               /* path-trace: SUM over samples (caller divides by spp) */
+  float u, v;                /* PixelCoord: u = image ROW, v = image COLUMN (src/app_utils.cpp:43) */
+  mi_hit_record h;
+} mi_trace_result;                                               /* 84 B */
+
+#define MI_FLAG_ERROR   ((uint16_t)1)
+#define MI_FLAG_ESCAPED ((uint16_t)2)
+#define MI_INVALID_GEOM ((uint16_t)0xFFFF)
+#define MI_INVALID_PRIM ((uint32_t)0xFFFFFFFFu)
+
+typedef struct {
+  float min_x, min_y, min_z;
+  uint32_t prim_or_second_child;   /* leaf: primID; interior: index of second child (first child = this+1) */
+  uint16_t dx, dy, dz;             /* IEEE binary16 bit patterns of the box extents, rounded up */
+  uint16_t geom_id;                /* 0xFFFF => interior node */
+} mi_bvh_node;                                                   /* 24 B, align 8 in the reference */
+
+typedef struct {
+  mi_vec3 albedo; float ior; mi_vec3 emission;
+  int32_t type;                    /* 0 Diffuse, 1 Specular, 2 Refractive (Material::Type) */
+  uint8_t emissive; uint8_t pad[3];
+} mi_material;                                                   /* 36 B */
+
+typedef struct {
+  uint32_t first_index, first_vertex, num_triangles, num_vertices;
+} mi_mesh_info;                                                  /* 16 B */
+
+typedef struct { uint16_t index; uint8_t type; uint8_t pad; } mi_geom_ref;   /* type: 0 mesh, 1 sphere, 2 disc */
+
+typedef struct { float x, y, z, radius; } mi_sphere;             /* radius2 = radius*radius is derived */
+typedef struct { float nx, ny, nz, r, cx, cy, cz; } mi_disc;     /* r2 = r*r is derived */
+
+/* ---- scene description: SceneRef + sphere/disc arrays + RuntimeConfig ---- */
+/* Mirrors reference include/Scene.hpp:50-74 (SceneRef) field for field, plus the
+ * two primitive arrays the IpuScene ctor takes separately (IpuScene.hpp:33-38).
+ * All pointers are HOST pointers owned by the caller; mi_scene_create copies
+ * what it needs to the device, so they may be freed after it returns.        */
+typedef struct {
+  const mi_geom_ref*  geometry;      uint32_t num_geometry;
+  const mi_mesh_info* mesh_info;     uint32_t num_meshes;
+  const uint16_t*     mesh_tris;     uint32_t num_tris;      /* 3 x u16 per triangle (Triangle, Primitives.hpp:21-25) */
+  const mi_vec3*      mesh_verts;    uint32_t num_verts;
+  const mi_vec3*      mesh_normals;  uint32_t num_normals;   /* 0, or == num_verts (--load-normals) */
+  const uint32_t*     mat_ids;       uint32_t num_mat_ids;   /* one per geometry */
+  const mi_material*  materials;     uint32_t num_materials;
+  const mi_bvh_node*  bvh_nodes;     uint32_t num_nodes;
+  uint32_t            max_leaf_depth;                        /* levels, root == 1 */
+  const mi_sphere*    spheres;       uint32_t num_spheres;
+  const mi_disc*      discs;         uint32_t num_discs;
+
+  float    image_width, image_height;      /* FULL image size, also when a crop window is rendered */
+  float    fov_radians;
+  float    anti_alias_scale;
+  uint32_t max_path_length;
+  uint32_t roulette_start_depth;
+  uint32_t samples_per_pixel;
+  uint64_t rng_seed;
+  int32_t  window_w, window_h, window_c, window_r;           /* CropWindow (Scene.hpp:22-27) */
+  int32_t  path_trace;                                       /* bool */
+  int32_t  device;                                           /* HIP device ordinal (RuntimeConfig analogue) */
+} mi_scene_desc;
+
+typedef struct mi_scene mi_scene;   /* opaque */
+
+/* Render modes: the two trace vertices of codelets/TraceCodelets.cpp:170-316 */
+enum { MI_MODE_SHADOW_TRACE = 0, MI_MODE_PATH_TRACE = 1 };
+
+/* Replaces: IpuScene::IpuScene(...) + setRuntimeConfig (src/IpuScene.cpp:24-62, trace.cpp:297-309) */
+int mi_scene_create(const mi_scene_desc* desc, mi_scene** out);
+
+/* Replaces: IpuScene::~IpuScene */
+void mi_scene_destroy(mi_scene* scene);
+
+/* Replaces: GraphManager().run(ipuScene) -> IpuScene::build + execute (src/IpuScene.cpp:346-733),
+ * host-buffer form. `rays` (n TraceResult, HOST memory) is read and overwritten in place exactly
+ * as the reference overwrites the caller's ray stream (src/IpuScene.cpp:716-732). In path-trace
+ * mode only rays[i].u/.v matter on input (camera rays are regenerated per sample on the device,
+ * codelets/TraceCodelets.cpp:142-164); rgb comes back as the sum over samples_per_pixel samples.
+ * In shadow-trace mode the given rays are traced as they are (Render.hpp:37-72).
+ * `cb` (may be NULL) mirrors IpuScene::RayCallbackFn: it is called once per completed batch with
+ * (user, batch_index, first_ray, ray_count) on the calling thread. */
+typedef void (*mi_ray_callback)(void* user, size_t batch_index, const mi_trace_result* rays, size_t count);
+int mi_render(mi_scene* scene, int mode, mi_trace_result* rays, size_t n, mi_ray_callback cb, void* user);
+
+/* Same operation on a DEVICE-resident ray stream (hipMalloc'ed / torch tensor memory), enqueued
+ * on `hip_stream` (a hipStream_t passed as void*; NULL = the null stream). Asynchronous: returns
+ * after enqueue. This is the entry bench.py times (inputs already resident in HBM). */
+int mi_render_device(mi_scene* scene, int mode, void* d_rays, size_t n, void* hip_stream);
+
+/* Replaces: IpuScene::getTraceTimeSecs (IpuScene.hpp:55). Wall time of the last mi_render. */
+double mi_trace_time_secs(const mi_scene* scene);
+
+/* Counters accumulated by render calls since scene creation / last reset: number of
+ * CompactBvh::intersect + ::occluded casts, BVH nodes visited, primitive (leaf) tests.
+ * Synchronises the device. counts[0]=casts, [1]=nodes visited, [2]=leaf tests, [3]=paths. */
+int mi_get_counters(mi_scene* scene, uint64_t counts[4]);
+int mi_reset_counters(mi_scene* scene);
+
+/* Replaces: IpuScene::loadNifModel (src/IpuScene.cpp:174-187) with the weights handed over as
+ * arrays (the reference's Keras-H5 file loader is out of scope).
+ * Dense layer i has kernel[i] of shape [rows[i] x cols[i]] row-major (Keras kernel:0 layout,
+ * y = x·W + b) and bias[i] of cols[i] floats (NULL = no bias); relu[i] != 0 applies ReLU.
+ * Where a layer's rows != current activation width, the Fourier features are re-concatenated
+ * to the activations first (NifModel.cpp:306-309). Decode: y*max + mean, then exp if
+ * log_tonemap (NifModel.cpp:222-246); `mean` must already have eps folded in
+ * (NifMetaData.cpp:48-53). Output channels are BGR (codelets/TraceCodelets.cpp:376). */
+int mi_scene_set_nif(mi_scene* scene, uint32_t num_layers,
+                     const float* const* kernels, const float* const* biases,
+                     const uint32_t* rows, const uint32_t* cols, const uint8_t* relu,
+                     uint32_t embedding_dimension, float max_value, const float mean[3],
+                     int32_t log_tonemap);
+
+/* Replaces: IpuScene::setHdriRotation (degrees) / setMaxNifBatchSize (src/IpuScene.cpp:334-344). */
+int mi_scene_set_hdri_rotation(mi_scene* scene, float degrees);
+int mi_scene_set_max_nif_batch(mi_scene* scene, size_t rays_per_batch);
+
+/* The NIF environment evaluated stand-alone on device arrays: for i<n, bgr[i*3..] =
+ * decode(MLP(fourier(u[i], v[i]))). Replaces NifModel::buildInference's execModel
+ * (NifModel.cpp:249-356). d_u, d_v, d_bgr are DEVICE pointers. */
+int mi_nif_infer_device(mi_scene* scene, const float* d_u, const float* d_v, float* d_bgr,
+                        size_t n, void* hip_stream);
+
+/* Thread-local message for the last failing call on this thread. Never NULL. */
+const char* mi_last_error(void);
+
+/* Library / build identification, e.g. "mi_raylib 0.1 gfx950 contract=off". */
+const char* mi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_RAYLIB_H */

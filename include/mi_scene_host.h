@@ -1,0 +1,60 @@
+/*
+ * mi_scene_host.h — C ABI of the host-side scene plumbing (CPU only, no GPU needed).
+ *
+ * These entry points reproduce the INPUTS the reference hands to its renderers — they are
+ * the callers' side of the hot path, not the hot path itself:
+ *   buildSceneDescription / makeCornellBoxScene / makePrimitiveScene  (src/app_utils.cpp:252-283,
+ *                                                                      src/scene_utils.cpp:319-597)
+ *   buildSceneData (array packing + BVH build driver)                 (src/app_utils.cpp:291-371)
+ *   BvhBuilder::build + buildCompactBvh (node FORMAT is contractual,  (include/embree_utils/bvh.hpp:37-77,
+ *     the Embree builder is not: tree topology is "parity unpinned")   src/CompactBvhBuild.cpp:5-56)
+ *   initPerspectiveRayStream (no-jitter form) + zeroRgb               (src/app_utils.cpp:19-53)
+ * The arrays they produce are what mi_scene_create (mi_raylib.h) and the CPU oracle consume.
+ */
+#ifndef MI_SCENE_HOST_H
+#define MI_SCENE_HOST_H
+
+#include "mi_raylib.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mi_host_scene mi_host_scene;   /* opaque; owns every array a desc points into */
+
+/* Built-in scenes of the reference CLI (--scene box-simple | box | spheres, trace.cpp:357).
+ * `mesh_file` is the glTF-binary mesh placed on the short block for "box"
+ * (assets/monkey_bust.glb in the reference, src/app_utils.cpp:264); ignored otherwise. */
+int mi_host_scene_builtin(const char* scene_name, const char* mesh_file, mi_host_scene** out);
+
+/* Build a scene from caller-provided arrays (same array contract as mi_scene_desc, but
+ * bvh_nodes/max_leaf_depth are ignored and rebuilt). Used by tests with synthetic geometry. */
+int mi_host_scene_from_arrays(const mi_scene_desc* geometry_only, mi_host_scene** out);
+
+/* Fill `desc` with pointers into the host scene's storage and the reference CLI's default
+ * render parameters (trace.cpp:343-366: 768x432, aa .25, path length 10, roulette depth 3,
+ * 256 spp, seed 1442; fov from the scene's camera). The desc stays valid until destroy. */
+int mi_host_scene_fill_desc(const mi_host_scene* scene, mi_scene_desc* desc);
+
+void mi_host_scene_destroy(mi_host_scene* scene);
+
+/* SAH BVH2 over axis-aligned boxes, one primitive per leaf, flattened depth-first with the
+ * first child adjacent to its parent (CompactBVH2Node.hpp:60-63). lower/upper: 3 floats per
+ * primitive. `nodes` must hold 2*n-1 entries. */
+int mi_build_compact_bvh(const float* lower, const float* upper, const uint16_t* geom_ids,
+                         const uint32_t* prim_ids, uint32_t n,
+                         mi_bvh_node* nodes, uint32_t* num_nodes, uint32_t* max_leaf_depth);
+
+/* initPerspectiveRayStream(rayStream, image, data, nullptr) + zeroRgb: window_w*window_h rays in
+ * row-major window order, origin 0, un-jittered pinhole directions, u=row, v=col. */
+int mi_init_ray_stream(const mi_scene_desc* desc, mi_trace_result* rays, size_t capacity);
+
+/* scaleRgb (src/app_utils.cpp:55-59) */
+void mi_scale_rgb(mi_trace_result* rays, size_t n, float scale);
+
+const char* mi_host_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

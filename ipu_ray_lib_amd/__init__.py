@@ -1,0 +1,306 @@
+"""ipu_ray_lib_amd — MI355X-native ray/path-trace hot path behind the reference's IpuScene surface.
+
+Python here is plumbing only: ctypes bindings over the two C-ABI shared libraries
+
+* ``libmi_scene_host.so``  (include/mi_scene_host.h) — CPU-side scene construction, BVH build,
+  ray-stream initialisation: the callers' side of the hot path;
+* ``libmi_raylib.so``      (include/mi_raylib.h)     — the gfx950 HIP kernels (shadow trace,
+  path trace, NIF MLP) and nothing else.
+
+There is NO CPU fallback for the device library: :func:`device_lib` raises if it is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+REPO_ROOT = PKG_DIR.parent
+DEFAULT_MESH = REPO_ROOT / "assets" / "monkey_bust.glb"
+
+# --------------------------------------------------------------------------------------------
+# POD layouts (== include/mi_raylib.h == the reference's structs)
+# --------------------------------------------------------------------------------------------
+VEC3 = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4")])
+RAY = np.dtype([("origin", VEC3), ("tMin", "<f4"), ("direction", VEC3), ("tMax", "<f4")])
+HIT = np.dtype([("r", RAY), ("primID", "<u4"), ("normal", VEC3), ("throughput", VEC3),
+                ("geomID", "<u2"), ("flags", "<u2")])
+TRACE_RESULT = np.dtype([("rgb", VEC3), ("u", "<f4"), ("v", "<f4"), ("h", HIT)])
+BVH_NODE = np.dtype([("min_x", "<f4"), ("min_y", "<f4"), ("min_z", "<f4"), ("link", "<u4"),
+                     ("dx", "<u2"), ("dy", "<u2"), ("dz", "<u2"), ("geomID", "<u2")])
+MATERIAL = np.dtype([("albedo", VEC3), ("ior", "<f4"), ("emission", VEC3), ("type", "<i4"),
+                     ("emissive", "u1"), ("pad", "u1", (3,))])
+MESH_INFO = np.dtype([("firstIndex", "<u4"), ("firstVertex", "<u4"), ("numTriangles", "<u4"), ("numVertices", "<u4")])
+GEOM_REF = np.dtype([("index", "<u2"), ("type", "u1"), ("pad", "u1")])
+SPHERE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("radius", "<f4")])
+DISC = np.dtype([("nx", "<f4"), ("ny", "<f4"), ("nz", "<f4"), ("r", "<f4"), ("cx", "<f4"), ("cy", "<f4"), ("cz", "<f4")])
+
+assert TRACE_RESULT.itemsize == 84 and HIT.itemsize == 64 and RAY.itemsize == 32
+assert BVH_NODE.itemsize == 24 and MATERIAL.itemsize == 36 and MESH_INFO.itemsize == 16 and GEOM_REF.itemsize == 4
+
+FLAG_ERROR, FLAG_ESCAPED = 1, 2
+INVALID_GEOM, INVALID_PRIM = 0xFFFF, 0xFFFFFFFF
+MODE_SHADOW_TRACE, MODE_PATH_TRACE = 0, 1
+
+MI_OK = 0
+
+
+class SceneDesc(C.Structure):
+    """mi_scene_desc (include/mi_raylib.h); the CPU oracle's ``oscene`` has the same layout."""
+    _fields_ = [
+        ("geometry", C.c_void_p), ("num_geometry", C.c_uint32),
+        ("mesh_info", C.c_void_p), ("num_meshes", C.c_uint32),
+        ("mesh_tris", C.c_void_p), ("num_tris", C.c_uint32),
+        ("mesh_verts", C.c_void_p), ("num_verts", C.c_uint32),
+        ("mesh_normals", C.c_void_p), ("num_normals", C.c_uint32),
+        ("mat_ids", C.c_void_p), ("num_mat_ids", C.c_uint32),
+        ("materials", C.c_void_p), ("num_materials", C.c_uint32),
+        ("bvh_nodes", C.c_void_p), ("num_nodes", C.c_uint32),
+        ("max_leaf_depth", C.c_uint32),
+        ("spheres", C.c_void_p), ("num_spheres", C.c_uint32),
+        ("discs", C.c_void_p), ("num_discs", C.c_uint32),
+        ("image_width", C.c_float), ("image_height", C.c_float),
+        ("fov_radians", C.c_float), ("anti_alias_scale", C.c_float),
+        ("max_path_length", C.c_uint32), ("roulette_start_depth", C.c_uint32),
+        ("samples_per_pixel", C.c_uint32),
+        ("rng_seed", C.c_uint64),
+        ("window_w", C.c_int32), ("window_h", C.c_int32), ("window_c", C.c_int32), ("window_r", C.c_int32),
+        ("path_trace", C.c_int32),
+        ("device", C.c_int32),
+    ]
+
+    def set_image(self, width: int, height: int, crop=None):
+        """--width/--height/--crop of the reference CLI (trace.cpp:475-479)."""
+        self.image_width, self.image_height = float(width), float(height)
+        if crop is None:
+            crop = (width, height, 0, 0)
+        self.window_w, self.window_h, self.window_c, self.window_r = crop
+        return self
+
+    @property
+    def num_rays(self) -> int:
+        return int(self.window_w) * int(self.window_h)
+
+
+class RaylibError(RuntimeError):
+    pass
+
+
+_host = None
+_device = None
+
+
+def _load(path: Path) -> C.CDLL:
+    if not path.exists():
+        raise RaylibError(f"{path.name} is not built (run `python -c 'import __graft_entry__ as g; g.build()'` at the repo root)")
+    return C.CDLL(str(path))
+
+
+def host_lib() -> C.CDLL:
+    """libmi_scene_host.so — CPU-only scene plumbing."""
+    global _host
+    if _host is None:
+        lib = _load(PKG_DIR / "libmi_scene_host.so")
+        lib.mi_host_last_error.restype = C.c_char_p
+        lib.mi_host_scene_builtin.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+        lib.mi_host_scene_from_arrays.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
+        lib.mi_host_scene_fill_desc.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
+        lib.mi_host_scene_destroy.argtypes = [C.c_void_p]
+        lib.mi_host_scene_destroy.restype = None
+        lib.mi_build_compact_bvh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                             C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        lib.mi_init_ray_stream.argtypes = [C.POINTER(SceneDesc), C.c_void_p, C.c_size_t]
+        lib.mi_scale_rgb.argtypes = [C.c_void_p, C.c_size_t, C.c_float]
+        lib.mi_scale_rgb.restype = None
+        _host = lib
+    return _host
+
+
+def device_lib() -> C.CDLL:
+    """libmi_raylib.so — the HIP kernels. Raises (never falls back) when it is not built."""
+    global _device
+    if _device is None:
+        lib = _load(PKG_DIR / "libmi_raylib.so")
+        lib.mi_last_error.restype = C.c_char_p
+        lib.mi_version.restype = C.c_char_p
+        lib.mi_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
+        lib.mi_scene_destroy.argtypes = [C.c_void_p]
+        lib.mi_scene_destroy.restype = None
+        lib.mi_render.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        lib.mi_render_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.mi_trace_time_secs.argtypes = [C.c_void_p]
+        lib.mi_trace_time_secs.restype = C.c_double
+        lib.mi_get_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        lib.mi_reset_counters.argtypes = [C.c_void_p]
+        lib.mi_scene_set_nif.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_int32]
+        lib.mi_scene_set_hdri_rotation.argtypes = [C.c_void_p, C.c_float]
+        lib.mi_scene_set_max_nif_batch.argtypes = [C.c_void_p, C.c_size_t]
+        lib.mi_nif_infer_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        _device = lib
+    return _device
+
+
+def _check_host(status: int):
+    if status != MI_OK:
+        raise RaylibError(f"host scene call failed ({status}): {host_lib().mi_host_last_error().decode()}")
+
+
+def _check_dev(status: int):
+    if status != MI_OK:
+        raise RaylibError(f"mi_raylib call failed ({status}): {device_lib().mi_last_error().decode()}")
+
+
+class HostScene:
+    """Scene arrays + CompactBVH built on the host (buildSceneDescription + buildSceneData,
+    reference src/app_utils.cpp:252-371). ``desc`` is the SceneRef analogue handed to renderers."""
+
+    def __init__(self, handle: C.c_void_p):
+        self._h = handle
+        self.desc = SceneDesc()
+        _check_host(host_lib().mi_host_scene_fill_desc(self._h, C.byref(self.desc)))
+
+    @classmethod
+    def builtin(cls, name: str = "box", mesh_file: os.PathLike | str | None = None) -> "HostScene":
+        mesh = str(mesh_file if mesh_file is not None else DEFAULT_MESH)
+        h = C.c_void_p()
+        _check_host(host_lib().mi_host_scene_builtin(name.encode(), mesh.encode(), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, geometry_desc: SceneDesc) -> "HostScene":
+        h = C.c_void_p()
+        _check_host(host_lib().mi_host_scene_from_arrays(C.byref(geometry_desc), C.byref(h)))
+        return cls(h)
+
+    def _view(self, ptr, count, dtype):
+        if not ptr or not count:
+            return np.zeros(0, dtype=dtype)
+        buf = (C.c_char * (count * dtype.itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype, count=count)
+
+    @property
+    def nodes(self):
+        return self._view(self.desc.bvh_nodes, self.desc.num_nodes, BVH_NODE)
+
+    @property
+    def verts(self):
+        return self._view(self.desc.mesh_verts, self.desc.num_verts, VEC3)
+
+    @property
+    def tris(self):
+        return self._view(self.desc.mesh_tris, self.desc.num_tris * 3, np.dtype("<u2")).reshape(-1, 3)
+
+    @property
+    def mesh_info(self):
+        return self._view(self.desc.mesh_info, self.desc.num_meshes, MESH_INFO)
+
+    @property
+    def geometry(self):
+        return self._view(self.desc.geometry, self.desc.num_geometry, GEOM_REF)
+
+    @property
+    def materials(self):
+        return self._view(self.desc.materials, self.desc.num_materials, MATERIAL)
+
+    @property
+    def mat_ids(self):
+        return self._view(self.desc.mat_ids, self.desc.num_mat_ids, np.dtype("<u4"))
+
+    @property
+    def spheres(self):
+        return self._view(self.desc.spheres, self.desc.num_spheres, SPHERE)
+
+    @property
+    def discs(self):
+        return self._view(self.desc.discs, self.desc.num_discs, DISC)
+
+    def init_ray_stream(self) -> np.ndarray:
+        """initPerspectiveRayStream (no jitter) + zeroRgb for the desc's window."""
+        rays = np.zeros(self.desc.num_rays, dtype=TRACE_RESULT)
+        _check_host(host_lib().mi_init_ray_stream(C.byref(self.desc), rays.ctypes.data, rays.size))
+        return rays
+
+    def close(self):
+        if self._h:
+            host_lib().mi_host_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class IpuScene:
+    """Mirror of the reference's ``IpuScene`` driver object (include/IpuScene.hpp:22-56) over the
+    C ABI: construct from a scene description, optionally load a NIF, ``run`` a ray stream."""
+
+    def __init__(self, desc: SceneDesc):
+        self._lib = device_lib()
+        self._h = C.c_void_p()
+        self.desc = desc
+        _check_dev(self._lib.mi_scene_create(C.byref(desc), C.byref(self._h)))
+
+    # -- reference API names -------------------------------------------------------------
+    def setHdriRotation(self, degrees: float):
+        _check_dev(self._lib.mi_scene_set_hdri_rotation(self._h, float(degrees)))
+
+    def setMaxNifBatchSize(self, rays_per_batch: int):
+        _check_dev(self._lib.mi_scene_set_max_nif_batch(self._h, int(rays_per_batch)))
+
+    def getTraceTimeSecs(self) -> float:
+        return float(self._lib.mi_trace_time_secs(self._h))
+
+    def setNif(self, kernels, biases, relu, embedding_dimension, max_value, mean, log_tonemap=True):
+        """Weights as arrays (the Keras-H5 loader of loadNifModel is a 'next' row)."""
+        n = len(kernels)
+        ks = [np.ascontiguousarray(k, dtype=np.float32) for k in kernels]
+        bs = [None if b is None else np.ascontiguousarray(b, dtype=np.float32) for b in biases]
+        kp = (C.c_void_p * n)(*[k.ctypes.data for k in ks])
+        bp = (C.c_void_p * n)(*[(b.ctypes.data if b is not None else None) for b in bs])
+        rows = np.array([k.shape[0] for k in ks], dtype=np.uint32)
+        cols = np.array([k.shape[1] for k in ks], dtype=np.uint32)
+        rl = np.array([1 if r else 0 for r in relu], dtype=np.uint8)
+        mean_a = np.ascontiguousarray(mean, dtype=np.float32)
+        _check_dev(self._lib.mi_scene_set_nif(self._h, n, kp, bp, rows.ctypes.data, cols.ctypes.data, rl.ctypes.data,
+                                              int(embedding_dimension), float(max_value), mean_a.ctypes.data,
+                                              1 if log_tonemap else 0))
+
+    def run(self, rays: np.ndarray, mode: int | None = None) -> np.ndarray:
+        """GraphManager().run(ipuScene): trace the HOST ray stream in place."""
+        assert rays.dtype == TRACE_RESULT and rays.flags["C_CONTIGUOUS"]
+        if mode is None:
+            mode = MODE_PATH_TRACE if self.desc.path_trace else MODE_SHADOW_TRACE
+        _check_dev(self._lib.mi_render(self._h, mode, rays.ctypes.data, rays.size, None, None))
+        return rays
+
+    def run_device(self, d_rays_ptr: int, n: int, mode: int, stream: int = 0):
+        """Trace a DEVICE-resident ray stream (e.g. a torch uint8 tensor's data_ptr) asynchronously."""
+        _check_dev(self._lib.mi_render_device(self._h, mode, C.c_void_p(d_rays_ptr), n, C.c_void_p(stream)))
+
+    def nif_infer_device(self, d_u: int, d_v: int, d_bgr: int, n: int, stream: int = 0):
+        _check_dev(self._lib.mi_nif_infer_device(self._h, C.c_void_p(d_u), C.c_void_p(d_v), C.c_void_p(d_bgr), n, C.c_void_p(stream)))
+
+    def counters(self) -> dict:
+        c = (C.c_uint64 * 4)()
+        _check_dev(self._lib.mi_get_counters(self._h, c))
+        return {"casts": c[0], "nodes_visited": c[1], "leaf_tests": c[2], "paths": c[3]}
+
+    def reset_counters(self):
+        _check_dev(self._lib.mi_reset_counters(self._h))
+
+    def close(self):
+        if self._h:
+            self._lib.mi_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,313 @@
+// nif_kernels.hpp — K3: the NIF neural environment light on gfx950 matrix cores.
+//
+//   escaped_uv_kernel   == PreProcessEscapedRays  (codelets/TraceCodelets.cpp:321-358) + wave-ballot
+//                          compaction of the escaped rays, so the MLP only runs on rays that need it
+//   nif_mlp_kernel      == NifModel::buildInference's execModel (src/neural_networks/NifModel.cpp:
+//                          186-246 encode/decode, :300-327 dense stack) with the env add of
+//                          PostProcessEscapedRays (codelets :361-382) fused into its epilogue
+//
+// Numerics follow the reference's fp16 model (--fp16 training, NifModel.cpp:212-216,
+// src/IpuScene.cpp:256-262): Fourier features are evaluated on binary16-rounded phases and rounded
+// to binary16; weights and inter-layer activations are binary16; products accumulate in binary32
+// on v_mfma_f32_16x16x32_f16 (the IPU accumulates in half: ours is the more accurate of the two).
+//
+// Kernel shape: one 256-thread workgroup owns 64 rays. Activations live in LDS as
+// [64][stride] binary16; the dense layers are evaluated transposed, Y^T = W^T · X^T, so that the
+// MFMA result fragment of a lane is 4 consecutive output features of ONE ray and goes back to LDS
+// as one 8-byte store. W^T is pre-packed on the host in exact A-fragment order, so every weight
+// load is a fully coalesced 1 KiB wave read served from L2.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "ray_math.h"
+#include "../../include/mi_raylib.h"
+
+namespace mi {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+constexpr uint32_t kNifRows = 64;        // rays per workgroup pass
+constexpr uint32_t kNifMaxLayers = 16;
+constexpr uint32_t kNifMaxTilesPerWave = 6;   // output-feature tiles (of 16) per wave: supports widths up to 384
+
+struct NifLayerDesc {
+  uint32_t kSteps;        // ceil(K/32)
+  uint32_t nTiles;        // ceil(N/16)
+  uint32_t n;             // real output width
+  uint32_t inBase;        // first LDS column of the layer's input
+  uint32_t wOffset;       // offset (in h8 units) of the packed weights
+  uint32_t bOffset;       // offset (floats) of the bias, 0xFFFFFFFF = none
+  uint32_t relu;
+};
+
+struct NifParams {
+  uint32_t numLayers, embedDim, featBase, stride;   // stride in halves
+  float maxValue, mean[3];
+  int32_t logTonemap;
+  NifLayerDesc layers[kNifMaxLayers];
+};
+
+struct NifDevice {
+  NifParams p{};
+  h8* d_weights = nullptr;
+  float* d_bias = nullptr;
+  uint32_t* d_count = nullptr;     // compaction counter
+  uint32_t* d_index = nullptr;     // compacted ray indices
+  size_t indexCap = 0;
+  bool ok = false;
+
+  bool loaded() const { return ok; }
+  void release() {
+    if (d_weights) (void)hipFree(d_weights);
+    if (d_bias) (void)hipFree(d_bias);
+    if (d_count) (void)hipFree(d_count);
+    if (d_index) (void)hipFree(d_index);
+    d_weights = nullptr; d_bias = nullptr; d_count = nullptr; d_index = nullptr; indexCap = 0; ok = false;
+  }
+
+  // Packs W (Keras [rows=K][cols=N], y = x·W) into A-fragment order of v_mfma_f32_16x16x32_f16 for the
+  // transposed product: fragment (nt, ks), lane l, element j = W[ks*32 + 8*(l>>4) + j][nt*16 + (l&15)].
+  void load(uint32_t numLayers, const float* const* kernels, const float* const* biases, const uint32_t* rows,
+            const uint32_t* cols, const uint8_t* relu, uint32_t embedDim, float maxValue, const float mean[3], int32_t logTonemap) {
+    release();
+    if (numLayers == 0 || numLayers > kNifMaxLayers) throw std::invalid_argument("NIF: unsupported number of layers");
+    if (embedDim == 0 || embedDim > 16) throw std::invalid_argument("NIF: embedding dimension must be 1..16");
+    const uint32_t F = 4 * embedDim;
+    uint32_t hidden = 0;
+    for (uint32_t l = 0; l + 1 < numLayers; ++l) hidden = cols[l] > hidden ? cols[l] : hidden;
+    if (numLayers == 1) hidden = 0;
+    const uint32_t featBase = (hidden + 31u) & ~31u;
+    if (cols[numLayers - 1] != 3) throw std::invalid_argument("NIF: last layer must have 3 outputs (BGR)");
+    NifParams P{};
+    P.numLayers = numLayers; P.embedDim = embedDim; P.featBase = featBase;
+    const uint32_t kPadMax = ((featBase + F + 31u) & ~31u);
+    P.stride = kPadMax + 8;                       // +8 halves: consecutive rows start 4 banks apart
+    P.maxValue = maxValue; P.mean[0] = mean[0]; P.mean[1] = mean[1]; P.mean[2] = mean[2]; P.logTonemap = logTonemap;
+    std::vector<_Float16> packed;
+    std::vector<float> bias;
+    uint32_t width = F;
+    bool inputIsFeatures = true;
+    for (uint32_t l = 0; l < numLayers; ++l) {
+      if (!kernels[l]) throw std::invalid_argument("NIF: null kernel");
+      const uint32_t K = rows[l], N = cols[l];
+      NifLayerDesc& L = P.layers[l];
+      if (inputIsFeatures) {
+        if (K != F) throw std::invalid_argument("NIF: first layer must take the " + std::to_string(F) + " Fourier features");
+        L.inBase = featBase;
+      } else if (K == width) {
+        L.inBase = 0;
+      } else if (K == width + F && width == featBase) {
+        L.inBase = 0;                              // activations followed by the features: the concat of NifModel.cpp:306-309
+      } else {
+        throw std::invalid_argument("NIF: layer " + std::to_string(l) + " input width does not match (concat needs a uniform hidden width that is a multiple of 32)");
+      }
+      if (N > 16 * kNifMaxTilesPerWave * 4) throw std::invalid_argument("NIF: layer too wide");
+      if (l + 1 < numLayers && N > featBase) throw std::invalid_argument("NIF: internal width error");
+      L.kSteps = (K + 31) / 32; L.nTiles = (N + 15) / 16; L.n = N; L.relu = relu[l] ? 1u : 0u;
+      L.wOffset = (uint32_t)(packed.size() / 8);
+      for (uint32_t nt = 0; nt < L.nTiles; ++nt)
+        for (uint32_t ks = 0; ks < L.kSteps; ++ks)
+          for (uint32_t lane = 0; lane < 64; ++lane)
+            for (uint32_t j = 0; j < 8; ++j) {
+              const uint32_t k = ks * 32 + 8 * (lane >> 4) + j, n = nt * 16 + (lane & 15);
+              const float w = (k < K && n < N) ? kernels[l][(size_t)k * N + n] : 0.f;
+              packed.push_back((_Float16)w);
+            }
+      if (biases && biases[l]) { L.bOffset = (uint32_t)bias.size(); for (uint32_t n = 0; n < N; ++n) bias.push_back(biases[l][n]); for (uint32_t n = N; n < L.nTiles * 16; ++n) bias.push_back(0.f); }
+      else L.bOffset = 0xFFFFFFFFu;
+      width = N;
+      inputIsFeatures = false;
+    }
+    if (hipMalloc(&d_weights, packed.size() * sizeof(_Float16)) != hipSuccess) throw std::runtime_error("NIF: hipMalloc failed");
+    (void)hipMemcpy(d_weights, packed.data(), packed.size() * sizeof(_Float16), hipMemcpyHostToDevice);
+    if (!bias.empty()) {
+      if (hipMalloc(&d_bias, bias.size() * sizeof(float)) != hipSuccess) throw std::runtime_error("NIF: hipMalloc failed");
+      (void)hipMemcpy(d_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice);
+    }
+    if (hipMalloc(&d_count, sizeof(uint32_t)) != hipSuccess) throw std::runtime_error("NIF: hipMalloc failed");
+    p = P;
+    ok = true;
+  }
+
+  void ensureIndex(size_t n) {
+    if (indexCap >= n) return;
+    if (d_index) (void)hipFree(d_index);
+    d_index = nullptr; indexCap = 0;
+    if (hipMalloc(&d_index, n * sizeof(uint32_t)) != hipSuccess) throw std::runtime_error("NIF: hipMalloc failed");
+    indexCap = n;
+  }
+};
+
+// PreProcessEscapedRays + compaction. u/v are written for EVERY ray (0 for rays that did not escape,
+// as the reference does); `index[0..*count)` receives the escaped rays' indices, one atomic per wave.
+__global__ void __launch_bounds__(256) escaped_uv_kernel(const mi_trace_result* rays, uint32_t n, float azimuthRotation,
+                                                         float* u, float* v, uint32_t* index, uint32_t* count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool escaped = false;
+  float uu = 0.f, vv = 0.f;
+  if (i < n) {
+    const mi_hit_record& h = rays[i].h;
+    if (h.flags & MI_FLAG_ESCAPED) {
+      escaped = true;
+      const float twoPi = (float)(2.0 * 3.14159265358979323846264338327950288);
+      const float invPi = (float)(1.0 / 3.14159265358979323846264338327950288);
+      const float inv2Pi = (float)(1.0 / (2.0 * 3.14159265358979323846264338327950288));
+      const float theta = acosf(h.r.direction.y);
+      float phi = atan2f(h.r.direction.z, h.r.direction.x) + azimuthRotation;
+      if (phi < 0.f) phi += twoPi;
+      else if (phi > twoPi) phi -= twoPi;
+      uu = theta * invPi;
+      vv = phi * inv2Pi;
+    }
+    u[i] = uu; v[i] = vv;
+  }
+  const unsigned long long mask = __ballot(escaped);
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t base = 0;
+  if (lane == 0 && mask) base = atomicAdd(count, (uint32_t)__popcll(mask));
+  base = __shfl(base, 0);
+  if (escaped) index[base + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+}
+
+// The MLP. rows: `numRows` (or *countPtr when countPtr != nullptr) entries; entry r reads
+// u[idx ? idx[r] : r], v[...]; result goes to bgrOut[3*r..] (stand-alone) and/or is added to
+// rays[idx[r]].rgb as throughput * (b,g,r)->(r,g,b) (PostProcessEscapedRays).
+__global__ void __launch_bounds__(256) nif_mlp_kernel(NifParams P, const h8* __restrict__ weights, const float* __restrict__ bias,
+                                                      const float* __restrict__ u, const float* __restrict__ v,
+                                                      const uint32_t* __restrict__ idx, const uint32_t* __restrict__ countPtr,
+                                                      uint32_t numRows, float* __restrict__ bgrOut, mi_trace_result* rays) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 X[];   // [kNifRows][P.stride]
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t total = countPtr ? *countPtr : numRows;
+  const uint32_t stride = P.stride;
+  const uint32_t E = P.embedDim, F = 4 * E;
+
+  for (uint32_t row0 = blockIdx.x * kNifRows; row0 < total; row0 += gridDim.x * kNifRows) {
+    __syncthreads();   // previous pass finished with X
+    // zero the K-padding columns behind the features, then write the Fourier features
+    for (uint32_t e = tid; e < kNifRows * (stride - P.featBase - F); e += blockDim.x) {
+      const uint32_t r = e / (stride - P.featBase - F), c = e % (stride - P.featBase - F);
+      X[r * stride + P.featBase + F + c] = (_Float16)0.f;
+    }
+    for (uint32_t e = tid; e < kNifRows * E * 2; e += blockDim.x) {
+      const uint32_t r = e / (2 * E), q = e % (2 * E), j = q % E, isV = q / E;
+      const uint32_t row = row0 + r;
+      float coord = 0.f;
+      if (row < total) { const uint32_t src = idx ? idx[row] : row; coord = isV ? v[src] : u[src]; }
+      const float nrm = (coord - 1.f) * 2.f;                                  // NifModel.cpp:203-205
+      const float phase = (float)(_Float16)(nrm * (float)(1u << j));           // cast to HALF before sin/cos (:212)
+      const _Float16 sn = (_Float16)sinf(phase), cs = (_Float16)cosf(phase);
+      // feature order [sin u | sin v | cos u | cos v] (NifModel.cpp:216)
+      X[r * stride + P.featBase + isV * E + j] = sn;
+      X[r * stride + P.featBase + 2 * E + isV * E + j] = cs;
+    }
+    __syncthreads();
+
+    for (uint32_t l = 0; l < P.numLayers; ++l) {
+      const NifLayerDesc L = P.layers[l];
+      f4v acc[kNifMaxTilesPerWave][4];
+#pragma unroll
+      for (uint32_t a = 0; a < kNifMaxTilesPerWave; ++a)
+#pragma unroll
+        for (uint32_t m = 0; m < 4; ++m) acc[a][m] = (f4v){0.f, 0.f, 0.f, 0.f};
+      // this wave's output-feature tiles: wave, wave+4, wave+8, ...
+      for (uint32_t ks = 0; ks < L.kSteps; ++ks) {
+        h8 xb[4];
+#pragma unroll
+        for (uint32_t m = 0; m < 4; ++m)   // B fragment: X^T[k][ray] = X[ray = 16m + (lane&15)][k = 32ks + 8(lane>>4) + j]
+          xb[m] = *reinterpret_cast<const h8*>(&X[(16 * m + (lane & 15)) * stride + L.inBase + 32 * ks + 8 * (lane >> 4)]);
+#pragma unroll
+        for (uint32_t a = 0; a < kNifMaxTilesPerWave; ++a) {
+          const uint32_t nt = wave + 4 * a;
+          if (nt < L.nTiles) {
+            const h8 wa = weights[L.wOffset + ((size_t)nt * L.kSteps + ks) * 64 + lane];
+#pragma unroll
+            for (uint32_t m = 0; m < 4; ++m) acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xb[m], acc[a][m], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();   // every wave has read its inputs: X[.., 0..N) may be overwritten
+      const bool last = (l + 1 == P.numLayers);
+#pragma unroll
+      for (uint32_t a = 0; a < kNifMaxTilesPerWave; ++a) {
+        const uint32_t nt = wave + 4 * a;
+        if (nt < L.nTiles) {
+          // D fragment: rows (= output features) 16nt + 4(lane>>4) + reg, column (= ray) 16m + (lane&15)
+          const uint32_t f0 = 16 * nt + 4 * (lane >> 4);
+#pragma unroll
+          for (uint32_t m = 0; m < 4; ++m) {
+            f4v y = acc[a][m];
+            if (L.bOffset != 0xFFFFFFFFu) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) y[q] += bias[L.bOffset + f0 + q];
+            }
+            if (L.relu) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) y[q] = y[q] > 0.f ? y[q] : 0.f;
+            }
+            const uint32_t r = 16 * m + (lane & 15);
+            if (!last) {
+              h4 yh = {(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
+              *reinterpret_cast<h4*>(&X[r * stride + f0]) = yh;
+            } else if (nt == 0 && (lane >> 4) == 0 && row0 + r < total) {
+              // decode (NifModel.cpp:222-246): y*max + mean, exp for log-tonemapped models
+              float o[3];
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                o[c] = y[c] * P.maxValue + P.mean[c];
+                if (P.logTonemap) o[c] = expf(o[c]);
+              }
+              const uint32_t row = row0 + r;
+              if (bgrOut) { bgrOut[3 * row] = o[0]; bgrOut[3 * row + 1] = o[1]; bgrOut[3 * row + 2] = o[2]; }
+              if (rays) {
+                mi_trace_result* res = rays + (idx ? idx[row] : row);
+                const mi_vec3 tp = res->h.throughput;
+                res->rgb.x += tp.x * o[2];          // BGR -> RGB (codelets/TraceCodelets.cpp:376)
+                res->rgb.y += tp.y * o[1];
+                res->rgb.z += tp.z * o[0];
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+inline void nif_launch_mlp(const NifDevice& nif, const float* u, const float* v, const uint32_t* idx, const uint32_t* countPtr,
+                           uint32_t numRows, float* bgrOut, mi_trace_result* rays, hipStream_t stream) {
+  if (numRows == 0) return;
+  const size_t lds = (size_t)kNifRows * nif.p.stride * sizeof(_Float16);
+  uint32_t blocks = (numRows + kNifRows - 1) / kNifRows;
+  if (blocks > 256 * 8) blocks = 256 * 8;          // grid-stride beyond 8 row-blocks per CU
+  hipLaunchKernelGGL(nif_mlp_kernel, dim3(blocks), dim3(256), lds, stream, nif.p, nif.d_weights, nif.d_bias, u, v, idx, countPtr,
+                     numRows, bgrOut, rays);
+}
+
+// mi_nif_infer_device: every row is evaluated (no compaction)
+inline void nif_infer(NifDevice& nif, const float* d_u, const float* d_v, float* d_bgr, size_t n, size_t maxBatch, hipStream_t stream) {
+  const size_t chunk = maxBatch ? maxBatch : n;
+  for (size_t off = 0; off < n; off += chunk) {
+    const size_t cnt = (n - off < chunk) ? (n - off) : chunk;
+    nif_launch_mlp(nif, d_u + off, d_v + off, nullptr, nullptr, (uint32_t)cnt, d_bgr + 3 * off, nullptr, stream);
+  }
+}
+
+// One sample's environment pass over the whole ray stream (src/IpuScene.cpp:571-583)
+inline void nif_env_pass(NifDevice& nif, mi_trace_result* d_rays, uint32_t n, float azimuthRadians, float* d_u, float* d_v,
+                         float* d_bgr, size_t /*maxBatch*/, hipStream_t stream) {
+  nif.ensureIndex(n);
+  (void)hipMemsetAsync(nif.d_count, 0, sizeof(uint32_t), stream);
+  hipLaunchKernelGGL(escaped_uv_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_rays, n, azimuthRadians, d_u, d_v, nif.d_index, nif.d_count);
+  nif_launch_mlp(nif, d_u, d_v, nif.d_index, nif.d_count, n, nullptr, d_rays, stream);
+}
+
+}  // namespace mi

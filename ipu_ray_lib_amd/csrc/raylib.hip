@@ -1,0 +1,372 @@
+// raylib.hip — C ABI (include/mi_raylib.h) over the gfx950 kernels: scene validation + upload,
+// kernel launches, counters, timing. This file is the whole device library (libmi_raylib.so).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mi_raylib.h"
+#include "ray_math.h"
+#include "trace_kernels.hpp"
+#include "nif_kernels.hpp"
+
+using namespace mi;
+
+static_assert(sizeof(mi_trace_result) == 84, "TraceResult layout");
+static_assert(sizeof(mi_hit_record) == 64, "HitRecord layout");
+static_assert(sizeof(mi_ray) == 32, "Ray layout");
+static_assert(sizeof(mi_bvh_node) == 24, "CompactBVH2Node layout");
+static_assert(sizeof(mi_material) == 36, "Material layout");
+static_assert(sizeof(mi_mesh_info) == 16 && sizeof(mi_geom_ref) == 4, "MeshInfo/GeomRef layout");
+static_assert(offsetof(mi_trace_result, u) == 12 && offsetof(mi_trace_result, h) == 20, "TraceResult offsets");
+static_assert(offsetof(mi_hit_record, prim_id) == 32 && offsetof(mi_hit_record, normal) == 36 &&
+              offsetof(mi_hit_record, throughput) == 48 && offsetof(mi_hit_record, geom_id) == 60 &&
+              offsetof(mi_hit_record, flags) == 62, "HitRecord offsets");
+
+namespace {
+
+thread_local std::string g_err;
+
+struct DeviceError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct ArgError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+#define HIP_CHECK(expr)                                                                      \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      throw DeviceError(std::string(#expr) + ": " + hipGetErrorString(_e));                  \
+  } while (0)
+
+template <class F>
+int guarded(F&& f) {
+  try { f(); g_err.clear(); return MI_OK; }
+  catch (const ArgError& e) { g_err = e.what(); return MI_ERR_INVALID_ARG; }
+  catch (const DeviceError& e) { g_err = e.what(); return MI_ERR_DEVICE; }
+  catch (const std::exception& e) { g_err = e.what(); return MI_ERR_DEVICE; }
+}
+
+template <class T>
+T* upload(const std::vector<T>& v) {
+  if (v.empty()) return nullptr;
+  T* d = nullptr;
+  HIP_CHECK(hipMalloc(&d, v.size() * sizeof(T)));
+  HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return d;
+}
+
+const float* hostSinTable() {
+  static const uint32_t bits[92] = {MI_SIN_TABLE_BITS};
+  static float tbl[92];
+  static bool init = false;
+  if (!init) { memcpy(tbl, bits, sizeof tbl); init = true; }
+  return tbl;
+}
+
+}  // namespace
+
+struct mi_scene {
+  int device = 0;
+  mi_scene_desc params{};            // scalar parameters only (pointers nulled)
+  DeviceScene ds{};
+  std::vector<void*> allocations;
+  unsigned long long* d_counters = nullptr;
+  double traceTimeSecs = 0.0;
+  float hdriRotationDegrees = 0.f;
+  size_t maxNifBatch = 0;
+  NifDevice nif;
+  // scratch for the per-sample NIF loop
+  Rng* d_rng = nullptr; float* d_u = nullptr; float* d_v = nullptr; float* d_bgr = nullptr; size_t scratchRays = 0;
+
+  ~mi_scene() {
+    (void)hipSetDevice(device);
+    for (void* p : allocations) (void)hipFree(p);
+    if (d_rng) (void)hipFree(d_rng);
+    if (d_u) (void)hipFree(d_u);
+    if (d_v) (void)hipFree(d_v);
+    if (d_bgr) (void)hipFree(d_bgr);
+    nif.release();
+  }
+  template <class T> T* keep(T* p) { if (p) allocations.push_back((void*)p); return p; }
+};
+
+namespace {
+
+// Validate everything the kernels will index with, then build the device arrays.
+void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
+  auto need = [](bool ok, const char* what) { if (!ok) throw ArgError(std::string("mi_scene_create: ") + what); };
+  need(d.num_nodes == 0 || d.bvh_nodes, "bvh_nodes is null");
+  need(d.num_geometry == 0 || d.geometry, "geometry is null");
+  need(d.num_geometry <= 0xFFFF, "more than 65535 geometries (geomID is 16 bit)");
+  need(d.num_mat_ids >= d.num_geometry, "All primitives must be assigned a material.");
+  need(d.num_mat_ids == 0 || d.mat_ids, "mat_ids is null");
+  need(d.num_materials == 0 || d.materials, "materials is null");
+  need(d.num_meshes == 0 || (d.mesh_info && d.mesh_tris && d.mesh_verts), "mesh arrays are null");
+  need(d.num_normals == 0 || (d.num_normals == d.num_verts && d.mesh_normals), "normals must be absent or one per vertex");
+  need(d.num_spheres == 0 || d.spheres, "spheres is null");
+  need(d.num_discs == 0 || d.discs, "discs is null");
+  need(d.image_width > 0.f && d.image_height > 0.f, "image size must be positive");
+  for (uint32_t g = 0; g < d.num_geometry; ++g) {
+    const mi_geom_ref& r = d.geometry[g];
+    need(r.type <= 2, "unknown geometry type");
+    need(r.index < (r.type == 0 ? d.num_meshes : r.type == 1 ? d.num_spheres : d.num_discs), "geometry index out of range");
+    need(d.mat_ids[g] < d.num_materials, "material index out of range");
+  }
+  for (uint32_t m = 0; m < d.num_meshes; ++m) {
+    const mi_mesh_info& mi_ = d.mesh_info[m];
+    need((uint64_t)mi_.first_index + mi_.num_triangles <= d.num_tris, "mesh triangle range out of bounds");
+    need((uint64_t)mi_.first_vertex + mi_.num_vertices <= d.num_verts, "mesh vertex range out of bounds");
+    for (uint32_t t = 0; t < 3 * mi_.num_triangles; ++t)
+      need(d.mesh_tris[3 * (size_t)mi_.first_index + t] < mi_.num_vertices, "triangle vertex index out of range");
+  }
+
+  // Node array: same bytes, interior link := skip index (preorder subtree end). Also checks that the
+  // array really is a preorder BVH2 (first child adjacent, second child after it, every node reached).
+  const uint32_t N = d.num_nodes;
+  std::vector<GNode> nodes(N);
+  std::vector<uint32_t> skip(N);
+  std::vector<GLeaf> leaves;
+  std::vector<uint32_t> geomFirstVertex(d.num_geometry, 0);
+  for (uint32_t g = 0; g < d.num_geometry; ++g)
+    if (d.geometry[g].type == 0) geomFirstVertex[g] = d.mesh_info[d.geometry[g].index].first_vertex;
+  for (uint32_t i = N; i-- > 0;) {
+    const mi_bvh_node& n = d.bvh_nodes[i];
+    if (n.geom_id != MI_INVALID_GEOM) skip[i] = i + 1;
+    else {
+      const uint32_t second = n.prim_or_second_child;
+      need(i + 1 < N && second > i + 1 && second < N, "BVH is not a depth-first BVH2 (bad second child index)");
+      need(skip[i + 1] == second, "BVH is not in depth-first order (first child's subtree must end at the second child)");
+      skip[i] = skip[second];
+    }
+  }
+  need(N == 0 || skip[0] == N, "BVH root does not span the node array");
+  for (uint32_t i = 0; i < N; ++i) {
+    const mi_bvh_node& n = d.bvh_nodes[i];
+    GNode g;
+    g.minx = n.min_x; g.miny = n.min_y; g.minz = n.min_z;
+    g.hx = n.dx; g.hy = n.dy; g.hz = n.dz; g.geomID = n.geom_id;
+    if (n.geom_id == MI_INVALID_GEOM) g.link = skip[i];
+    else {
+      need(n.geom_id < d.num_geometry, "leaf geomID out of range");
+      const mi_geom_ref& r = d.geometry[n.geom_id];
+      GLeaf L;
+      memset(&L, 0, sizeof L);
+      if (r.type == 0) {
+        const mi_mesh_info& mi_ = d.mesh_info[r.index];
+        need(n.prim_or_second_child < mi_.num_triangles, "leaf primID out of range");
+        const size_t base = 3 * ((size_t)mi_.first_index + n.prim_or_second_child);
+        for (int k = 0; k < 3; ++k) {
+          const mi_vec3& p = d.mesh_verts[mi_.first_vertex + d.mesh_tris[base + k]];
+          L.f[3 * k] = p.x; L.f[3 * k + 1] = p.y; L.f[3 * k + 2] = p.z;
+        }
+        L.type = LEAF_TRI; L.primID = n.prim_or_second_child; L.triBase = (uint32_t)base;
+      } else if (r.type == 1) {
+        const mi_sphere& s = d.spheres[r.index];
+        L.f[0] = s.x; L.f[1] = s.y; L.f[2] = s.z; L.f[3] = s.radius; L.f[4] = s.radius * s.radius;   // Primitives.hpp:44
+        L.type = LEAF_SPHERE; L.primID = 0;                                                           // Primitives.cpp:45
+      } else {
+        const mi_disc& c = d.discs[r.index];
+        L.f[0] = c.nx; L.f[1] = c.ny; L.f[2] = c.nz; L.f[3] = c.cx; L.f[4] = c.cy; L.f[5] = c.cz; L.f[6] = c.r * c.r;
+        L.type = LEAF_DISC; L.primID = 0;
+      }
+      g.link = (uint32_t)leaves.size();
+      leaves.push_back(L);
+    }
+    nodes[i] = g;
+  }
+
+  DeviceScene& ds = S.ds;
+  ds.nodes = S.keep(upload(nodes)); ds.numNodes = N;
+  ds.leaves = S.keep(upload(leaves)); ds.numLeaves = (uint32_t)leaves.size();
+  ds.matIDs = S.keep(upload(std::vector<uint32_t>(d.mat_ids, d.mat_ids + d.num_mat_ids)));
+  ds.materials = S.keep(upload(std::vector<mi_material>(d.materials, d.materials + d.num_materials)));
+  ds.numMaterials = d.num_materials;
+  ds.hasNormals = d.num_normals ? 1u : 0u;
+  if (ds.hasNormals) {
+    ds.meshTris = S.keep(upload(std::vector<uint16_t>(d.mesh_tris, d.mesh_tris + 3 * (size_t)d.num_tris)));
+    ds.meshNormals = S.keep(upload(std::vector<mi_vec3>(d.mesh_normals, d.mesh_normals + d.num_normals)));
+    ds.geomFirstVertex = S.keep(upload(geomFirstVertex));
+  }
+  ds.imageWidth = d.image_width; ds.imageHeight = d.image_height;
+  float s, c;
+  sincos_deg_table(d.fov_radians / 2.f, hostSinTable(), s, c);   // codelets/TraceCodelets.cpp:147-149
+  ds.tanTheta = s / c;
+  ds.antiAliasScale = d.anti_alias_scale;
+  ds.maxPathLength = d.max_path_length; ds.rouletteStartDepth = d.roulette_start_depth;
+  ds.samplesPerPixel = d.samples_per_pixel;
+  ds.rngSeed = d.rng_seed;
+  HIP_CHECK(hipMalloc(&S.d_counters, 4 * sizeof(unsigned long long)));
+  S.keep(S.d_counters);
+  HIP_CHECK(hipMemset(S.d_counters, 0, 4 * sizeof(unsigned long long)));
+  ds.counters = S.d_counters;
+}
+
+void ensureScratch(mi_scene& S, size_t n) {
+  if (S.scratchRays >= n) return;
+  if (S.d_rng) (void)hipFree(S.d_rng);
+  if (S.d_u) (void)hipFree(S.d_u);
+  if (S.d_v) (void)hipFree(S.d_v);
+  if (S.d_bgr) (void)hipFree(S.d_bgr);
+  S.d_rng = nullptr; S.d_u = S.d_v = S.d_bgr = nullptr; S.scratchRays = 0;
+  HIP_CHECK(hipMalloc(&S.d_rng, n * sizeof(Rng)));
+  HIP_CHECK(hipMalloc(&S.d_u, n * sizeof(float)));
+  HIP_CHECK(hipMalloc(&S.d_v, n * sizeof(float)));
+  HIP_CHECK(hipMalloc(&S.d_bgr, 3 * n * sizeof(float)));
+  S.scratchRays = n;
+}
+
+bool g_fullStats = false;
+
+void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipStream_t stream) {
+  if (n == 0) return;
+  if (n > 0xFFFFFFFFull) throw ArgError("mi_render: more than 2^32-1 rays in one call");
+  const uint32_t cnt = (uint32_t)n;
+  const dim3 block(256), grid((cnt + 255) / 256);
+  if (mode == MI_MODE_SHADOW_TRACE) {
+    const f3 light = mk(18.f, 257.f, -1060.f);          // trace.cpp:247, src/IpuScene.cpp:447
+    if (g_fullStats) hipLaunchKernelGGL(shadow_trace_kernel<true>, grid, block, 0, stream, S.ds, d_rays, cnt, .05f, light);
+    else hipLaunchKernelGGL(shadow_trace_kernel<false>, grid, block, 0, stream, S.ds, d_rays, cnt, .05f, light);
+  } else if (mode == MI_MODE_PATH_TRACE) {
+    if (!S.nif.loaded()) {
+      // sample loop inside the kernel (src/IpuScene.cpp:441: vertexSampleCount = samplesPerPixel)
+      if (g_fullStats) hipLaunchKernelGGL(path_trace_kernel<true>, grid, block, 0, stream, S.ds, d_rays, cnt, 0u, S.ds.samplesPerPixel, (Rng*)nullptr);
+      else hipLaunchKernelGGL(path_trace_kernel<false>, grid, block, 0, stream, S.ds, d_rays, cnt, 0u, S.ds.samplesPerPixel, (Rng*)nullptr);
+    } else {
+      // Repeat(spp){ trace 1 sample; uv pre-pass; NIF; env post-pass }  (src/IpuScene.cpp:571-583)
+      ensureScratch(S, n);
+      const float radians = (S.hdriRotationDegrees / 360.f) * (float)(2.0 * M_PI);   // src/IpuScene.cpp:644
+      for (uint32_t s = 0; s < S.ds.samplesPerPixel; ++s) {
+        if (g_fullStats) hipLaunchKernelGGL(path_trace_kernel<true>, grid, block, 0, stream, S.ds, d_rays, cnt, s, 1u, S.d_rng);
+        else hipLaunchKernelGGL(path_trace_kernel<false>, grid, block, 0, stream, S.ds, d_rays, cnt, s, 1u, S.d_rng);
+        nif_env_pass(S.nif, d_rays, cnt, radians, S.d_u, S.d_v, S.d_bgr, S.maxNifBatch, stream);
+      }
+    }
+  } else {
+    throw ArgError("mi_render: unknown render mode");
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mi_last_error(void) { return g_err.c_str(); }
+
+const char* mi_version(void) { return "mi_raylib 0.1 gfx950 fp-contract=off (bit-exact to the reference CPU path)"; }
+
+int mi_scene_create(const mi_scene_desc* desc, mi_scene** out) {
+  if (!desc || !out) { g_err = "mi_scene_create: null argument"; return MI_ERR_INVALID_ARG; }
+  *out = nullptr;
+  mi_scene* S = nullptr;
+  const int rc = guarded([&] {
+    int count = 0;
+    HIP_CHECK(hipGetDeviceCount(&count));
+    if (count <= 0) throw DeviceError("no HIP device available (the product path has no CPU fallback)");
+    if (desc->device < 0 || desc->device >= count) throw ArgError("mi_scene_create: device ordinal out of range");
+    HIP_CHECK(hipSetDevice(desc->device));
+    S = new mi_scene;
+    S->device = desc->device;
+    S->params = *desc;
+    buildDeviceScene(*S, *desc);
+    // the caller's arrays are not referenced after this point
+    S->params.geometry = nullptr; S->params.mesh_info = nullptr; S->params.mesh_tris = nullptr; S->params.mesh_verts = nullptr;
+    S->params.mesh_normals = nullptr; S->params.mat_ids = nullptr; S->params.materials = nullptr; S->params.bvh_nodes = nullptr;
+    S->params.spheres = nullptr; S->params.discs = nullptr;
+    if (const char* e = getenv("MI_RAYLIB_FULL_STATS")) g_fullStats = (e[0] == '1');
+  });
+  if (rc != MI_OK) { delete S; return rc; }
+  *out = S;
+  return MI_OK;
+}
+
+void mi_scene_destroy(mi_scene* scene) { delete scene; }
+
+int mi_render_device(mi_scene* scene, int mode, void* d_rays, size_t n, void* hip_stream) {
+  if (!scene || (!d_rays && n)) { g_err = "mi_render_device: null argument"; return MI_ERR_INVALID_ARG; }
+  return guarded([&] {
+    HIP_CHECK(hipSetDevice(scene->device));
+    launchRender(*scene, mode, (mi_trace_result*)d_rays, n, (hipStream_t)hip_stream);
+  });
+}
+
+int mi_render(mi_scene* scene, int mode, mi_trace_result* rays, size_t n, mi_ray_callback cb, void* user) {
+  if (!scene || (!rays && n)) { g_err = "mi_render: null argument"; return MI_ERR_INVALID_ARG; }
+  return guarded([&] {
+    HIP_CHECK(hipSetDevice(scene->device));
+    if (n == 0) { scene->traceTimeSecs = 0.0; return; }
+    mi_trace_result* d = nullptr;
+    HIP_CHECK(hipMalloc(&d, n * sizeof(mi_trace_result)));
+    try {
+      HIP_CHECK(hipMemcpy(d, rays, n * sizeof(mi_trace_result), hipMemcpyHostToDevice));
+      const auto t0 = std::chrono::steady_clock::now();     // like src/IpuScene.cpp:692-696: upload excluded
+      launchRender(*scene, mode, d, n, nullptr);
+      HIP_CHECK(hipDeviceSynchronize());
+      scene->traceTimeSecs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      HIP_CHECK(hipMemcpy(rays, d, n * sizeof(mi_trace_result), hipMemcpyDeviceToHost));
+    } catch (...) { (void)hipFree(d); throw; }
+    HIP_CHECK(hipFree(d));
+    if (cb) cb(user, 0, rays, n);
+  });
+}
+
+double mi_trace_time_secs(const mi_scene* scene) { return scene ? scene->traceTimeSecs : 0.0; }
+
+int mi_get_counters(mi_scene* scene, uint64_t counts[4]) {
+  if (!scene || !counts) { g_err = "mi_get_counters: null argument"; return MI_ERR_INVALID_ARG; }
+  return guarded([&] {
+    HIP_CHECK(hipSetDevice(scene->device));
+    HIP_CHECK(hipDeviceSynchronize());
+    unsigned long long h[4];
+    HIP_CHECK(hipMemcpy(h, scene->d_counters, sizeof h, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; ++i) counts[i] = h[i];
+  });
+}
+
+int mi_reset_counters(mi_scene* scene) {
+  if (!scene) { g_err = "mi_reset_counters: null argument"; return MI_ERR_INVALID_ARG; }
+  return guarded([&] {
+    HIP_CHECK(hipSetDevice(scene->device));
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemset(scene->d_counters, 0, 4 * sizeof(unsigned long long)));
+  });
+}
+
+int mi_scene_set_nif(mi_scene* scene, uint32_t num_layers, const float* const* kernels, const float* const* biases,
+                     const uint32_t* rows, const uint32_t* cols, const uint8_t* relu,
+                     uint32_t embedding_dimension, float max_value, const float mean[3], int32_t log_tonemap) {
+  if (!scene || !kernels || !rows || !cols || !relu || !mean) { g_err = "mi_scene_set_nif: null argument"; return MI_ERR_INVALID_ARG; }
+  return guarded([&] {
+    HIP_CHECK(hipSetDevice(scene->device));
+    try { scene->nif.load(num_layers, kernels, biases, rows, cols, relu, embedding_dimension, max_value, mean, log_tonemap); }
+    catch (const std::invalid_argument& e) { throw ArgError(e.what()); }
+  });
+}
+
+int mi_scene_set_hdri_rotation(mi_scene* scene, float degrees) {
+  if (!scene) { g_err = "null scene"; return MI_ERR_INVALID_ARG; }
+  scene->hdriRotationDegrees = degrees;
+  return MI_OK;
+}
+
+int mi_scene_set_max_nif_batch(mi_scene* scene, size_t rays_per_batch) {
+  if (!scene) { g_err = "null scene"; return MI_ERR_INVALID_ARG; }
+  scene->maxNifBatch = rays_per_batch;
+  return MI_OK;
+}
+
+int mi_nif_infer_device(mi_scene* scene, const float* d_u, const float* d_v, float* d_bgr, size_t n, void* hip_stream) {
+  if (!scene || ((!d_u || !d_v || !d_bgr) && n)) { g_err = "mi_nif_infer_device: null argument"; return MI_ERR_INVALID_ARG; }
+  if (!scene->nif.loaded()) { g_err = "mi_nif_infer_device: no NIF model loaded"; return MI_ERR_NO_NIF; }
+  return guarded([&] {
+    HIP_CHECK(hipSetDevice(scene->device));
+    nif_infer(scene->nif, d_u, d_v, d_bgr, n, scene->maxNifBatch, (hipStream_t)hip_stream);
+    HIP_CHECK(hipGetLastError());
+  });
+}
+
+}  // extern "C"

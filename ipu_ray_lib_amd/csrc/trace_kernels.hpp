@@ -1,0 +1,401 @@
+// trace_kernels.hpp — gfx950 kernels for the ray-parallel hot path:
+//   K2 shadow_trace_kernel  == ShadowTrace vertex  (codelets/TraceCodelets.cpp:269-316, Render.hpp:37-72)
+//   K1 path_trace_kernel    == PathTrace vertex    (codelets/TraceCodelets.cpp:170-264 == trace.cpp:115-188)
+//
+// Traversal design. The reference walks the depth-first CompactBVH2Node array with a
+// per-ray stack, always first child first (CompactBvh.hpp:80-139). Because the array is in
+// preorder, "pop the next entry" is always the node that follows the current node's subtree, so the
+// same visit order is produced by a STACKLESS walk: box hit on an interior node -> i+1, anything
+// else -> skip(i) where skip(i) = i + subtree size (i+1 for leaves). The upload step rewrites the
+// interior nodes' link word from secondChildIndex to that skip index; no per-wavefront stack, no
+// LDS or scratch traffic for it, and every lane's sequence of box tests, primitive tests and
+// closest-hit updates is exactly the reference's.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "ray_math.h"
+#include "../../include/mi_raylib.h"
+
+namespace mi {
+
+// ---- device scene ---------------------------------------------------------------------------------
+struct __attribute__((aligned(8))) GNode {       // 24 B, same bytes as CompactBVH2Node except `link`
+  float minx, miny, minz;
+  uint32_t link;                                  // interior: skip index; leaf: index into leaves[]
+  uint16_t hx, hy, hz;                            // binary16 extents
+  uint16_t geomID;                                // 0xFFFF = interior
+};
+static_assert(sizeof(GNode) == 24, "GNode must stay 24 bytes");
+
+enum : uint32_t { LEAF_TRI = 0, LEAF_SPHERE = 1, LEAF_DISC = 2 };
+
+struct __attribute__((aligned(16))) GLeaf {       // 48 B pre-resolved primitive
+  float f[9];        // tri: p0,p1,p2 | sphere: cx,cy,cz,radius,radius2 | disc: nx,ny,nz,cx,cy,cz,r2
+  uint32_t type;     // LEAF_*
+  uint32_t primID;   // value reported in the hit record
+  uint32_t triBase;  // tri: index of the triangle's first u16 in meshTris (for vertex normals)
+};
+static_assert(sizeof(GLeaf) == 48, "GLeaf must stay 48 bytes");
+
+struct DeviceScene {
+  const GNode* nodes;        uint32_t numNodes;
+  const GLeaf* leaves;       uint32_t numLeaves;
+  const uint32_t* matIDs;    // per geomID
+  const mi_material* materials; uint32_t numMaterials;
+  // vertex normals (only when the scene was loaded with normals)
+  const uint16_t* meshTris; const mi_vec3* meshNormals; const uint32_t* geomFirstVertex; uint32_t hasNormals;
+  float imageWidth, imageHeight, tanTheta, antiAliasScale;
+  uint32_t maxPathLength, rouletteStartDepth, samplesPerPixel;
+  uint64_t rngSeed;
+  unsigned long long* counters;   // [casts, nodes visited, leaf tests, paths]
+};
+
+struct Shear { uint32_t kz; float sx, sy, sz; };
+
+// Primitives.cpp:5-22. Pure function of the ray, so it is evaluated once per cast instead of once
+// per leaf (Mesh.hpp:89); identical values.
+__device__ __forceinline__ Shear make_shear(f3 d) {
+  Shear s;
+  s.kz = min_index(d);
+  uint32_t kx = s.kz + 1; if (kx == 3) kx = 0;
+  uint32_t ky = kx + 1; if (ky == 3) ky = 0;
+  const float dx = comp(d, kx), dy = comp(d, ky), dz = comp(d, s.kz);
+  s.sx = -dx / dz;
+  s.sy = -dy / dz;
+  s.sz = 1.f / dz;
+  return s;
+}
+
+__device__ __forceinline__ f3 permute_kz(f3 p, uint32_t kz) {
+  // (kx,ky,kz) is the cyclic rotation that puts component kz last
+  if (kz == 2) return p;
+  if (kz == 0) return mk(p.y, p.z, p.x);
+  return mk(p.z, p.x, p.y);
+}
+
+// Mesh.cpp:6-104 (ALLOW_DOUBLE_FALLBACK=0), tFar = inf as passed by Mesh.hpp:92. Returns t (0 = miss).
+__device__ __forceinline__ float intersect_triangle(f3 p0, f3 p1, f3 p2, f3 o, const Shear& sh, float& b0, float& b1, float& b2) {
+  f3 p0t = permute_kz(p0 - o, sh.kz), p1t = permute_kz(p1 - o, sh.kz), p2t = permute_kz(p2 - o, sh.kz);
+  p0t.x += sh.sx * p0t.z; p0t.y += sh.sy * p0t.z;
+  p1t.x += sh.sx * p1t.z; p1t.y += sh.sy * p1t.z;
+  p2t.x += sh.sx * p2t.z; p2t.y += sh.sy * p2t.z;
+  const float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+  const float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+  const float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+  if ((e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0)) return 0.f;
+  const float det = e0 + e1 + e2;
+  if (det == 0) return 0.f;
+  p0t.z *= sh.sz; p1t.z *= sh.sz; p2t.z *= sh.sz;
+  const float tScaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+  const float tFar = kInf;
+  if (det < 0.f && (tScaled >= 0.f || tScaled < tFar * det)) return 0.f;
+  else if (det > 0.f && (tScaled <= 0.f || tScaled > tFar * det)) return 0.f;
+  const float invDet = 1 / det;
+  b0 = e0 * invDet; b1 = e1 * invDet; b2 = e2 * invDet;
+  const float t = tScaled * invDet;
+  const float maxZt = min_comp(abs3(mk(p0t.z, p1t.z, p2t.z)));
+  const float deltaZ = gamma_n(3) * maxZt;
+  const float maxXt = min_comp(abs3(mk(p0t.x, p1t.x, p2t.x)));
+  const float maxYt = min_comp(abs3(mk(p0t.y, p1t.y, p2t.y)));
+  const float deltaX = gamma_n(5) * (maxXt + maxZt);
+  const float deltaY = gamma_n(5) * (maxYt + maxZt);
+  const float deltaE = 2 * (gamma_n(2) * maxXt * maxYt + deltaY * maxXt + deltaX * maxYt);
+  const float maxE = min_comp(abs3(mk(e0, e1, e2)));
+  const float deltaT = 3 * (gamma_n(3) * maxE * maxZt + deltaE * maxZt + deltaZ * maxE) * fabsf(invDet);
+  if (t <= deltaT) return 0.f;
+  return t;
+}
+
+// Primitives.cpp:24-47
+__device__ __forceinline__ float intersect_sphere(const GLeaf& L, f3 o, f3 d, float tMin) {
+  const float radius2 = L.f[4];
+  const f3 f = mk(L.f[0], L.f[1], L.f[2]) - o;
+  const float rd2 = 1.f / sqnorm(d);
+  const float tca = dot(f, d) * rd2;
+  if (tca < 0.f) return 0.f;
+  const f3 l = f - d * tca;
+  const float l2 = sqnorm(l);
+  if (l2 > radius2) return 0.f;
+  const float td = sqrtf(radius2 - l2) * rd2;
+  float t0 = tca - td, t1 = tca + td;
+  if (t0 > t1) { const float tmp = t0; t0 = t1; t1 = tmp; }
+  if (t0 < tMin) {
+    t0 = t1;
+    if (t0 < tMin) return 0.f;
+  }
+  return t0;
+}
+
+// Primitives.cpp:49-67
+__device__ __forceinline__ float intersect_disc(const GLeaf& L, f3 o, f3 d) {
+  const f3 n = mk(L.f[0], L.f[1], L.f[2]), c = mk(L.f[3], L.f[4], L.f[5]);
+  const float r2 = L.f[6];
+  const float angle = dot(n, d);
+  if (angle != 0.f) {
+    const float dd = fabsf(dot(c, n));
+    const float t = -(dot(n, o) + dd) / angle;
+    if (t > kMachineEps) {
+      const f3 hp = o + d * t;
+      const float d2 = sqnorm(hp - c);
+      if (d2 < r2) return t;
+    }
+  }
+  return 0.f;
+}
+
+struct Hit {
+  float t;            // closest t so far (starts at ray.tMax)
+  uint32_t leaf;      // 0xFFFFFFFF = none
+  uint32_t geomID;
+  float b0, b1, b2;   // barycentrics of the closest triangle hit (vertex-normal scenes)
+};
+
+struct CastStats { uint32_t nodes, leaves; };
+
+// CompactBvh::intersect (ANY_HIT=false, CompactBvh.hpp:80-139) / ::occluded (ANY_HIT=true, :33-78).
+// Box test: CompactBVH2Node.cpp:5-22 + intersectRaySlab (CompactBVH2Node.hpp:14-50). All three
+// slabs are evaluated before the single t0>t1 test; since t0 only grows and t1 only shrinks across
+// the axes, that is the same predicate as the reference's per-axis early outs.
+template <bool ANY_HIT, bool STATS>
+__device__ __forceinline__ bool traverse(const DeviceScene& sc, f3 o, f3 d, float tMin, float tMax, Hit& hit, CastStats& cs) {
+  const f3 inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+  const Shear sh = make_shear(d);
+  hit.t = tMax; hit.leaf = 0xFFFFFFFFu; hit.geomID = 0xFFFFu; hit.b0 = hit.b1 = hit.b2 = 0.f;
+  const uint32_t numNodes = sc.numNodes;
+  uint32_t i = 0;
+  while (i < numNodes) {
+    const GNode nd = sc.nodes[i];
+    if (STATS) cs.nodes++;
+    float t0 = tMin, t1 = hit.t;
+    {
+      const float maxx = nd.minx + half_bits_to_float(nd.hx);
+      float tmin = (nd.minx - o.x) * inv.x, tmax = (maxx - o.x) * inv.x;
+      if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; }
+      tmax *= kSlabScale;
+      t0 = tmin > t0 ? tmin : t0;
+      t1 = tmax < t1 ? tmax : t1;
+    }
+    {
+      const float maxy = nd.miny + half_bits_to_float(nd.hy);
+      float tmin = (nd.miny - o.y) * inv.y, tmax = (maxy - o.y) * inv.y;
+      if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; }
+      tmax *= kSlabScale;
+      t0 = tmin > t0 ? tmin : t0;
+      t1 = tmax < t1 ? tmax : t1;
+    }
+    {
+      const float maxz = nd.minz + half_bits_to_float(nd.hz);
+      float tmin = (nd.minz - o.z) * inv.z, tmax = (maxz - o.z) * inv.z;
+      if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; }
+      tmax *= kSlabScale;
+      t0 = tmin > t0 ? tmin : t0;
+      t1 = tmax < t1 ? tmax : t1;
+    }
+    const bool boxHit = !(t0 > t1);
+    const bool isLeaf = nd.geomID != 0xFFFFu;
+    if (boxHit && isLeaf) {
+      if (STATS) cs.leaves++;
+      const GLeaf L = sc.leaves[nd.link];
+      float t, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+      bool cand;
+      if (L.type == LEAF_TRI) {
+        t = intersect_triangle(mk(L.f[0], L.f[1], L.f[2]), mk(L.f[3], L.f[4], L.f[5]), mk(L.f[6], L.f[7], L.f[8]), o, sh, b0, b1, b2);
+        cand = t > 0.f && t < kInf;                 // Mesh.hpp:93
+      } else if (L.type == LEAF_SPHERE) {
+        t = intersect_sphere(L, o, d, tMin);
+        cand = true;                                // Failed() carries t = 0, rejected by t > tMin below
+      } else {
+        t = intersect_disc(L, o, d);
+        cand = true;
+      }
+      if (cand && t > tMin && t < hit.t) {          // CompactBvh.hpp:124 / :60 (hit.t == ray.tMax for any-hit)
+        if (ANY_HIT) return true;
+        hit.t = t; hit.leaf = nd.link; hit.geomID = nd.geomID; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2;
+      }
+    }
+    // next node in the reference's visit order
+    i = (boxHit && !isLeaf) ? i + 1 : (isLeaf ? i + 1 : nd.link);
+  }
+  return hit.leaf != 0xFFFFFFFFu;
+}
+
+// Primitive::normal for the closest hit (Mesh.hpp:107-121, Primitives.hpp:48-50,72). `hp` is the
+// advanced ray origin (Render.hpp:21-22).
+__device__ __forceinline__ f3 hit_normal(const DeviceScene& sc, const Hit& h, f3 hp) {
+  const GLeaf L = sc.leaves[h.leaf];
+  if (L.type == LEAF_TRI) {
+    if (!sc.hasNormals) {
+      const f3 p0 = mk(L.f[0], L.f[1], L.f[2]), p1 = mk(L.f[3], L.f[4], L.f[5]), p2 = mk(L.f[6], L.f[7], L.f[8]);
+      return normalized(cross(p1 - p0, p2 - p0));
+    }
+    const uint32_t fv = sc.geomFirstVertex[h.geomID];
+    const mi_vec3 a = sc.meshNormals[fv + sc.meshTris[L.triBase]];
+    const mi_vec3 b = sc.meshNormals[fv + sc.meshTris[L.triBase + 1]];
+    const mi_vec3 c = sc.meshNormals[fv + sc.meshTris[L.triBase + 2]];
+    return normalized((mk(a.x, a.y, a.z) * h.b0) + (mk(b.x, b.y, b.z) * h.b1) + (mk(c.x, c.y, c.z) * h.b2));
+  }
+  if (L.type == LEAF_SPHERE) return normalized(hp - mk(L.f[0], L.f[1], L.f[2]));
+  return mk(L.f[0], L.f[1], L.f[2]);
+}
+
+__device__ __forceinline__ void flush_stats(const DeviceScene& sc, uint32_t casts, const CastStats& cs, uint32_t paths) {
+  // one atomic per wave and counter
+  unsigned long long c = casts, n = cs.nodes, l = cs.leaves, p = paths;
+  for (int off = 32; off > 0; off >>= 1) {
+    c += __shfl_down(c, off); n += __shfl_down(n, off); l += __shfl_down(l, off); p += __shfl_down(p, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&sc.counters[0], c);
+    if (n) atomicAdd(&sc.counters[1], n);
+    if (l) atomicAdd(&sc.counters[2], l);
+    if (p) atomicAdd(&sc.counters[3], p);
+  }
+}
+
+__constant__ uint32_t kSinBits[92] = {MI_SIN_TABLE_BITS};
+
+__device__ __forceinline__ void load_sin_table(float* tbl) {
+  for (uint32_t k = threadIdx.x; k < 92; k += blockDim.x) tbl[k] = __uint_as_float(kSinBits[k]);
+  __syncthreads();
+}
+
+// ---- K2: shadow trace ---------------------------------------------------------------------------------
+template <bool STATS>
+__global__ void __launch_bounds__(256) shadow_trace_kernel(DeviceScene sc, mi_trace_result* rays, uint32_t n, float ambient, f3 lightPos) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  CastStats cs = {0, 0};
+  uint32_t casts = 0;
+  if (idx < n) {
+    mi_trace_result* res = rays + idx;
+    const mi_hit_record h = res->h;
+    f3 o = mk(h.r.origin.x, h.r.origin.y, h.r.origin.z), d = mk(h.r.direction.x, h.r.direction.y, h.r.direction.z);
+    Hit hit;
+    ++casts;
+    if (traverse<false, STATS>(sc, o, d, h.r.t_min, h.r.t_max, hit, cs)) {
+      // updateHit, Render.hpp:15-23
+      const f3 hp = o + d * hit.t;
+      const f3 nrm = hit_normal(sc, hit, hp);
+      const mi_material mat = sc.materials[sc.matIDs[hit.geomID]];
+      const f3 lightOffset = lightPos - hp;
+      const f3 sd = normalized(lightOffset);
+      const f3 so = offset_origin(hp, sd, nrm);
+      const float sTmax = sqrtf(sqnorm(lightOffset));
+      const f3 albedo = mk(mat.albedo.x, mat.albedo.y, mat.albedo.z);
+      f3 color = albedo * ambient;
+      Hit shadowHit;
+      ++casts;
+      if (!traverse<true, STATS>(sc, so, sd, 0.f, sTmax, shadowHit, cs)) color = color + albedo * dot(sd, nrm);
+      res->rgb = {color.x, color.y, color.z};
+      res->h.r.origin = {hp.x, hp.y, hp.z};
+      res->h.r.t_max = hit.t;
+      res->h.prim_id = sc.leaves[hit.leaf].primID;
+      res->h.normal = {nrm.x, nrm.y, nrm.z};
+      res->h.geom_id = (uint16_t)hit.geomID;
+    } else {
+      res->h.flags = h.flags | MI_FLAG_ESCAPED;
+    }
+  }
+  flush_stats(sc, casts, cs, idx < n ? 1u : 0u);
+}
+
+// ---- K1: path trace -----------------------------------------------------------------------------------
+// One lane owns one pixel's ray-stream entry and runs all samplesPerPixel samples of it, like a
+// worker of the PathTrace vertex runs the sample loop inside the vertex (codelets :191). Random
+// numbers come from the lane's own xoroshiro128** stream.
+struct PathState {
+  f3 o, d, n, tp;
+  float tMax;
+  uint32_t primID, geomID, flags;
+};
+
+template <bool STATS>
+__global__ void __launch_bounds__(256) path_trace_kernel(DeviceScene sc, mi_trace_result* rays, uint32_t n, uint32_t firstSample, uint32_t numSamples, Rng* rngStates) {
+  __shared__ float sinTbl[92];
+  load_sin_table(sinTbl);
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  CastStats cs = {0, 0};
+  uint32_t casts = 0, paths = 0;
+  if (idx < n) {
+    mi_trace_result* res = rays + idx;
+    const float prow = res->u, pcol = res->v;
+    Rng rng;
+    if (rngStates && firstSample != 0) rng = rngStates[idx];
+    else rng_seed_pixel(rng, sc.rngSeed, prow, pcol);
+    f3 rgb = mk(res->rgb.x, res->rgb.y, res->rgb.z);
+    PathState ps;
+    ps.flags = 0; ps.primID = MI_INVALID_PRIM; ps.geomID = MI_INVALID_GEOM; ps.tMax = kInf;
+    ps.o = mk(0, 0, 0); ps.d = mk(0, 0, -1); ps.n = mk(0, 0, 1); ps.tp = mk(1, 1, 1);
+    for (uint32_t s = 0; s < numSamples; ++s) {
+      // sampleCameraRays, codelets/TraceCodelets.cpp:142-164
+      float g0, g1;
+      rng_gauss2(rng, sinTbl, g0, g1);
+      const float jr = prow + sc.antiAliasScale * g0, jc = pcol + sc.antiAliasScale * g1;
+      ps.d = pixel_to_ray_dir(jc, jr, sc.imageWidth, sc.imageHeight, sc.tanTheta);
+      ps.o = mk(0.f, 0.f, 0.f);
+      ps.n = mk(0.f, 0.f, 1.f);                       // HitRecord ctor, geometry.hpp:236-242
+      ps.primID = MI_INVALID_PRIM; ps.geomID = MI_INVALID_GEOM; ps.flags = 0; ps.tMax = kInf;
+      ps.tp = mk(1.f, 1.f, 1.f);
+      f3 color = mk(0.f, 0.f, 0.f);
+      for (uint32_t i = 0; i < sc.maxPathLength; ++i) {
+        ps.o = offset_origin(ps.o, ps.d, ps.n);
+        Hit hit;
+        ++casts;
+        if (traverse<false, STATS>(sc, ps.o, ps.d, 0.f, kInf, hit, cs)) {
+          // updateHit
+          ps.geomID = hit.geomID;
+          ps.primID = sc.leaves[hit.leaf].primID;
+          ps.tMax = hit.t;
+          ps.o = ps.o + ps.d * hit.t;
+          ps.n = hit_normal(sc, hit, ps.o);
+          const mi_material mat = sc.materials[sc.matIDs[hit.geomID]];
+          const f3 albedo = mk(mat.albedo.x, mat.albedo.y, mat.albedo.z);
+          if (mat.emissive) color = color + ps.tp * mk(mat.emission.x, mat.emission.y, mat.emission.z);
+          if (mat.type == 0) {
+            const float u1 = rng_uniform01(rng);
+            const float u2 = rng_uniform01(rng);
+            ps.d = sample_diffuse(ps.n, u1, u2, sinTbl);
+            ps.tp = ps.tp * albedo;
+          } else if (mat.type == 1) {
+            ps.d = reflect_dir(ps.d, ps.n);
+            ps.tp = ps.tp * albedo;
+          } else if (mat.type == 2) {
+            const float u1 = rng_uniform01(rng);
+            f3 nd;
+            const bool refracted = dielectric(ps.d, ps.n, mat.ior, u1, nd);
+            ps.d = nd;
+            if (refracted) ps.tp = ps.tp * albedo;
+          } else {
+            rgb = rgb * __builtin_nanf("");
+            ps.flags |= MI_FLAG_ERROR;
+          }
+        } else {
+          ps.tMax = kInf;
+          ps.flags |= MI_FLAG_ESCAPED;
+          break;
+        }
+        if (i > sc.rouletteStartDepth) {
+          const float u1 = rng_uniform01(rng);
+          if (roulette_stop(u1, ps.tp)) break;
+        }
+      }
+      rgb = rgb + color;
+      ++paths;
+    }
+    if (rngStates) rngStates[idx] = rng;
+    if (numSamples) {
+      res->rgb = {rgb.x, rgb.y, rgb.z};
+      mi_hit_record hr;
+      hr.r.origin = {ps.o.x, ps.o.y, ps.o.z}; hr.r.t_min = 0.f;
+      hr.r.direction = {ps.d.x, ps.d.y, ps.d.z}; hr.r.t_max = ps.tMax;
+      hr.prim_id = ps.primID;
+      hr.normal = {ps.n.x, ps.n.y, ps.n.z};
+      hr.throughput = {ps.tp.x, ps.tp.y, ps.tp.z};
+      hr.geom_id = (uint16_t)ps.geomID; hr.flags = (uint16_t)ps.flags;
+      res->h = hr;
+    }
+  }
+  flush_stats(sc, casts, cs, paths);
+}
+
+}  // namespace mi

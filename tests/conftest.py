@@ -1,0 +1,22 @@
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_cpu_libs():
+    """CPU-side artefacts (oracle + host scene library) are built on demand; the HIP library is
+    built by __graft_entry__.build() and is only needed by -m gpu tests."""
+    import __graft_entry__ as ge
+    ge.build_cpu()
