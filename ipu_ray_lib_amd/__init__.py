@@ -123,6 +123,13 @@ def device_lib() -> C.CDLL:
     """libmi_raylib.so — the HIP kernels. Raises (never falls back) when it is not built."""
     global _device
     if _device is None:
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 (same SONAME as the
+        # system one libmi_raylib.so links to). Importing torch FIRST makes both resolve to the same
+        # already-loaded runtime; the other order leaves torch unable to see the GPU afterwards.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = _load(PKG_DIR / "libmi_raylib.so")
         lib.mi_last_error.restype = C.c_char_p
         lib.mi_version.restype = C.c_char_p

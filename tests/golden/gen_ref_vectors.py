@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/ref_l0_vectors.npz from the REFERENCE's own code.
+
+Run in the build container only (needs /root/reference): `make -C oracle ref` compiles the
+reference's Eigen-free L0 sources where they lie (ext/math/sincos.cpp, include/xoshiro.hpp,
+include/embree_utils/geometry.hpp, include/geometric_sampling.hpp, include/BxDF.hpp) behind the
+thin extern "C" driver oracle/ref_driver.cpp. This script drives that library with seeded inputs
+and stores inputs + outputs as DATA. No reference source text is stored.
+"""
+import ctypes as C
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import oracle_lib  # noqa: E402
+
+f32 = C.c_float
+
+
+def arr3(v):
+    return (f32 * 3)(*[float(x) for x in v])
+
+
+def main():
+    r = oracle_lib.ref_lib()
+    if r is None:
+        raise SystemExit("oracle/_ref/libref_l0.so missing: run `make -C oracle ref` where /root/reference exists")
+    rng = np.random.default_rng(20260410)
+    out = {}
+
+    # sincos: dense sweep over [-4pi, 4pi] plus special points
+    xs = np.concatenate([np.linspace(-4 * np.pi, 4 * np.pi, 20001), rng.uniform(-50, 50, 5000),
+                         [0.0, np.pi / 8, np.pi / 4, np.pi / 2, np.pi, 2 * np.pi, 1e-8, -1e-8, 1e-3, 100.0, -1000.0, np.pi / 4 / 2]]).astype(np.float32)
+    s = np.zeros_like(xs); c = np.zeros_like(xs)
+    for i, x in enumerate(xs):
+        a, b = f32(), f32()
+        r.ref_sincos(float(x), C.byref(a), C.byref(b))
+        s[i], c[i] = a.value, b.value
+    out.update(sincos_x=xs, sincos_s=s, sincos_c=c)
+
+    # maxi / maxc incl. ties, negatives, zeros
+    v = np.concatenate([rng.normal(size=(2000, 3)), rng.integers(-2, 3, size=(500, 3)).astype(np.float64),
+                        [[1, 2, 3], [3, 2, 1], [2, 1, 3], [1, 1, 1], [0, 0, 0], [-1, -2, -3], [1, 1, 0], [0, 1, 0]]]).astype(np.float32)
+    mi = np.array([r.ref_maxi(float(a), float(b), float(cc)) for a, b, cc in v], dtype=np.uint32)
+    mc = np.array([r.ref_maxc(float(a), float(b), float(cc)) for a, b, cc in v], dtype=np.float32)
+    out.update(maxi_v=v, maxi_i=mi, maxi_c=mc)
+
+    # xoshiro: seeds -> state, 16 outputs, 16 uniforms, jump
+    seeds = np.array([0, 1, 1442, 2**63, 2**64 - 1, 123456789, 0xDEADBEEF], dtype=np.uint64)
+    states = np.zeros((len(seeds), 2), dtype=np.uint64)
+    nexts = np.zeros((len(seeds), 16), dtype=np.uint64)
+    unis = np.zeros((len(seeds), 16), dtype=np.float32)
+    jumped = np.zeros((len(seeds), 2), dtype=np.uint64)
+    for i, sd in enumerate(seeds):
+        st = (C.c_uint64 * 2)()
+        r.ref_xoshiro_seed(st, int(sd)); states[i] = (st[0], st[1])
+        for k in range(16):
+            nexts[i, k] = r.ref_xoshiro_next(st)
+        r.ref_xoshiro_seed(st, int(sd))
+        for k in range(16):
+            unis[i, k] = r.ref_xoshiro_uniform01(st)
+        r.ref_xoshiro_seed(st, int(sd)); r.ref_xoshiro_jump(st); jumped[i] = (st[0], st[1])
+    sm_in = rng.integers(0, 2**63, size=64, dtype=np.uint64)
+    sm_out = np.array([r.ref_splitmix64(int(z)) for z in sm_in], dtype=np.uint64)
+    out.update(xo_seeds=seeds, xo_states=states, xo_next=nexts, xo_uniform=unis, xo_jump=jumped, sm_in=sm_in, sm_out=sm_out)
+
+    # sampling / BxDFs
+    n = 3000
+    u1 = rng.random(n).astype(np.float32); u2 = rng.random(n).astype(np.float32)
+    u1[:6] = [0.5, 0.5, 0.0, 1.0, 0.25, 0.75]; u2[:6] = [0.5, 0.25, 0.0, 1.0, 0.75, 0.25]
+    nrm = rng.normal(size=(n, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True); nrm = nrm.astype(np.float32)
+    nrm[:4] = [[0, 1, 0], [1, 0, 0], [0, 0, 1], [0, 0, -1]]
+    dirs = rng.normal(size=(n, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True); dirs = dirs.astype(np.float32)
+    disc = np.zeros((n, 2), np.float32); hemi = np.zeros((n, 3), np.float32); diff = np.zeros((n, 3), np.float32)
+    refl = np.zeros((n, 3), np.float32); ortho = np.zeros((n, 6), np.float32)
+    for i in range(n):
+        a, b = f32(), f32()
+        r.ref_sample_disc_concentric(float(u1[i]), float(u2[i]), C.byref(a), C.byref(b)); disc[i] = (a.value, b.value)
+        o = (f32 * 3)(); r.ref_cosine_sample_hemisphere(float(u1[i]), float(u2[i]), o); hemi[i] = list(o)
+        r.ref_sample_diffuse(arr3(nrm[i]), float(u1[i]), float(u2[i]), o); diff[i] = list(o)
+        r.ref_reflect(arr3(dirs[i]), arr3(nrm[i]), o); refl[i] = list(o)
+        b0, b1 = (f32 * 3)(), (f32 * 3)(); r.ref_orthonormal_system(arr3(nrm[i]), b0, b1); ortho[i] = list(b0) + list(b1)
+    out.update(bx_u1=u1, bx_u2=u2, bx_n=nrm, bx_d=dirs, bx_disc=disc, bx_hemi=hemi, bx_diffuse=diff, bx_reflect=refl, bx_ortho=ortho)
+
+    cosT = rng.uniform(-1, 1, n).astype(np.float32); ri = rng.choice([1.52, 1 / 1.52, 1.33, 2.4], n).astype(np.float32)
+    sch = np.array([r.ref_schlick(float(a), float(b)) for a, b in zip(cosT, ri)], dtype=np.float32)
+    die = np.zeros((n, 3), np.float32); die_flag = np.zeros(n, np.int32); refr = np.zeros((n, 3), np.float32)
+    ior = rng.choice([1.52, 1.33, 1.0, 2.4], n).astype(np.float32)
+    for i in range(n):
+        o = (f32 * 3)()
+        die_flag[i] = r.ref_dielectric(arr3([0, 0, 0]), arr3(dirs[i]), arr3(nrm[i]), float(ior[i]), float(u1[i]), o); die[i] = list(o)
+        ndotr = float(np.float32(np.dot(nrm[i].astype(np.float64), dirs[i].astype(np.float64))))
+        r.ref_refract(arr3(dirs[i]), arr3(nrm[i]), ndotr, float(ri[i]), o); refr[i] = list(o)
+    out.update(bx_cos=cosT, bx_ri=ri, bx_schlick=sch, bx_ior=ior, bx_dielectric=die, bx_dielectric_refracted=die_flag, bx_refract=refr)
+
+    tp = rng.random((n, 3)).astype(np.float32); tp[:3] = [[0.9, 0.5, 0.2], [0, 0.5, 0.5], [1, 1, 1]]
+    ur = rng.random(n).astype(np.float32); ur[0] = 0.1
+    tp_out = np.zeros_like(tp); stop = np.zeros(n, np.int32)
+    for i in range(n):
+        t = arr3(tp[i]); stop[i] = r.ref_evaluate_roulette(float(ur[i]), t); tp_out[i] = list(t)
+    out.update(rr_tp=tp, rr_u=ur, rr_tp_out=tp_out, rr_stop=stop)
+
+    lay = (C.c_uint32 * 12)(); r.ref_layout(lay)
+    out["layout"] = np.array(list(lay), dtype=np.uint32)
+
+    dst = Path(__file__).with_name("ref_l0_vectors.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, dst.stat().st_size, "bytes")
+
+
+if __name__ == "__main__":
+    main()

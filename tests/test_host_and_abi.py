@@ -1,0 +1,177 @@
+"""CPU tests of the host plumbing and of the C-ABI surface (no GPU compute is attempted).
+
+* built-in scenes match the reference's inventory (SURVEY.md §8 head: box = 6 Cornell meshes +
+  Cylinder + Suzanne + 2 spheres + 1 disc => 4035 leaves / 8069 nodes, matIDs {4,0,1,2,0,5,0,0,3,7,6});
+* the BVH array obeys the CompactBVH2Node contract (src/CompactBvhBuild.cpp:5-56);
+* the un-jittered ray stream equals the oracle's restatement of initPerspectiveRayStream;
+* both shared libraries load and export every symbol their header declares.
+"""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import ipu_ray_lib_amd as irl
+import oracle_lib as ol
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def half(a):
+    return np.asarray(a, dtype=np.uint16).view(np.float16).astype(np.float32)
+
+
+@pytest.mark.parametrize("name,nodes,tris,geoms", [("box-simple", 63, 32, 6), ("box", 8069, 4032, 11), ("spheres", 11, 0, 6)])
+def test_builtin_scene_inventory(name, nodes, tris, geoms):
+    s = irl.HostScene.builtin(name)
+    assert (s.desc.num_nodes, s.desc.num_tris, s.desc.num_geometry) == (nodes, tris, geoms)
+    if name == "box":
+        assert list(s.mat_ids) == [4, 0, 1, 2, 0, 5, 0, 0, 3, 7, 6]
+        assert [int(m["numTriangles"]) for m in s.mesh_info] == [2, 6, 2, 2, 10, 10, 64, 3936]
+        assert s.desc.num_materials == 8 and s.desc.num_spheres == 2 and s.desc.num_discs == 1
+        assert np.float32(s.desc.fov_radians) == np.float32(np.pi / 4)
+        light = s.materials[4]
+        assert light["emissive"] == 1 and np.allclose([light["emission"][k] for k in "xyz"], [13.333333, 7.6949024, 1.7976471])
+        # scene is camera-at-origin, looking down -z: all geometry in front of the camera
+        assert s.verts["z"].max() < 0
+    if name == "spheres":
+        assert np.float32(s.desc.fov_radians) == np.float32(np.pi / 2) and s.desc.num_spheres == 5
+
+
+@pytest.mark.parametrize("name", ["box-simple", "box", "spheres"])
+def test_compact_bvh_contract(name):
+    s = irl.HostScene.builtin(name)
+    n = s.nodes
+    N = len(n)
+    leaf = n["geomID"] != 0xFFFF
+    assert leaf.sum() * 2 - 1 == N                                  # full binary tree, one primitive per leaf
+    lo = np.stack([n["min_x"], n["min_y"], n["min_z"]], 1)
+    ext = np.stack([half(n["dx"]), half(n["dy"]), half(n["dz"])], 1)
+    hi = lo + ext
+    # preorder walk: first child adjacent, second child = node after the first child's subtree
+    depth_max = 0
+    seen = np.zeros(N, bool)
+    stack = [(0, 1)]
+    end = {}
+    order = []
+    while stack:
+        i, dpt = stack.pop()
+        seen[i] = True; order.append(i); depth_max = max(depth_max, dpt)
+        if not leaf[i]:
+            second = int(n["link"][i])
+            assert i + 1 < second < N
+            stack.append((second, dpt + 1)); stack.append((i + 1, dpt + 1))
+    assert seen.all() and order == list(range(N))                   # depth-first order IS array order
+    assert depth_max == s.desc.max_leaf_depth
+    # every interior box contains both children (half extents are rounded UP, so up to float rounding of min+ext)
+    for i in np.nonzero(~leaf)[0]:
+        for c in (i + 1, int(n["link"][i])):
+            # each node rounds its own extents up to binary16 (11 significant bits), so allow one half-ulp of the larger box
+            assert np.all(lo[c] >= lo[i]) and np.all(hi[c] <= hi[i] + ext[i] * 2.0 ** -9 + 1e-3)
+    # leaves: each (geomID, primID) exactly once, and the leaf box is the primitive's box with extents rounded up
+    pairs = set()
+    for i in np.nonzero(leaf)[0]:
+        g, p = int(n["geomID"][i]), int(n["link"][i])
+        assert (g, p) not in pairs
+        pairs.add((g, p))
+        ref = s.geometry[g]
+        if ref["type"] == 0:
+            mi = s.mesh_info[ref["index"]]
+            tri = s.tris[mi["firstIndex"] + p]
+            pv = np.array([[s.verts[mi["firstVertex"] + int(k)][c] for c in "xyz"] for k in tri], dtype=np.float32)
+            assert np.array_equal(lo[i], pv.min(0))
+            d = pv.max(0) - pv.min(0)
+            want = np.array([ol.lib().o_round_to_half_not_smaller(float(x)) for x in d], dtype=np.uint16)
+            assert np.array_equal(np.array([n["dx"][i], n["dy"][i], n["dz"][i]], dtype=np.uint16), want)
+    expected = sum(int(s.mesh_info[r["index"]]["numTriangles"]) if r["type"] == 0 else 1 for r in s.geometry)
+    assert len(pairs) == expected
+
+
+def test_ray_stream_matches_oracle_restatement():
+    s = irl.HostScene.builtin("box-simple")
+    for (w, h, crop) in [(512, 512, None), (1440, 1440, (37, 19, 700, 300)), (768, 432, None)]:
+        s.desc.set_image(w, h, crop)
+        got = s.init_ray_stream()
+        want = np.zeros_like(got)
+        ol.lib().o_init_ray_stream(C.byref(s.desc), want.ctypes.data)
+        assert got.tobytes() == want.tobytes()
+    # PixelCoord.u = ROW, .v = COLUMN in full-image coordinates even under --crop
+    s.desc.set_image(1440, 1440, (4, 3, 100, 200))
+    r = s.init_ray_stream()
+    assert r.size == 12 and r["u"][0] == 200 and r["v"][0] == 100 and r["u"][-1] == 202 and r["v"][-1] == 103
+    assert np.all(np.isinf(r["h"]["r"]["tMax"])) and np.all(r["h"]["geomID"] == 0xFFFF) and np.all(r["h"]["normal"]["z"] == 1)
+
+
+def test_host_error_behaviour():
+    h = C.c_void_p()
+    lib = irl.host_lib()
+    assert lib.mi_host_scene_builtin(b"no-such-scene", None, C.byref(h)) == 1        # MI_ERR_INVALID_ARG
+    assert b"Invalid scene selection" in lib.mi_host_last_error()
+    assert lib.mi_host_scene_builtin(b"box", b"/nonexistent/file.glb", C.byref(h)) == 4   # MI_ERR_IO
+    assert lib.mi_host_scene_builtin(None, None, C.byref(h)) == 1
+
+
+def test_bvh_builder_generic_boxes():
+    rng = np.random.default_rng(1)
+    for n in (1, 2, 3, 17, 500):
+        lo = rng.uniform(-100, 100, (n, 3)).astype(np.float32)
+        hi = lo + rng.uniform(0, 5, (n, 3)).astype(np.float32)
+        if n == 17:
+            lo[:] = lo[0]; hi[:] = hi[0]                          # all boxes identical: degenerate SAH
+        gid = np.zeros(n, np.uint16); pid = np.arange(n, dtype=np.uint32)
+        nodes = np.zeros(2 * n - 1, dtype=irl.BVH_NODE)
+        cnt, depth = C.c_uint32(), C.c_uint32()
+        rc = irl.host_lib().mi_build_compact_bvh(lo.ctypes.data, hi.ctypes.data, gid.ctypes.data, pid.ctypes.data, n,
+                                                 nodes.ctypes.data, C.byref(cnt), C.byref(depth))
+        assert rc == 0 and cnt.value == 2 * n - 1
+        leaves = nodes[nodes["geomID"] != 0xFFFF]
+        assert sorted(leaves["link"].tolist()) == list(range(n))
+        assert depth.value >= int(np.ceil(np.log2(n))) + 1
+    # an extent above the largest finite half is an error, as in the reference (CompactBvhBuild.cpp:15-18)
+    lo = np.zeros((2, 3), np.float32); hi = np.array([[1, 1, 1], [70000, 1, 1]], np.float32)
+    nodes = np.zeros(3, dtype=irl.BVH_NODE); cnt, depth = C.c_uint32(), C.c_uint32()
+    rc = irl.host_lib().mi_build_compact_bvh(lo.ctypes.data, hi.ctypes.data, np.zeros(2, np.uint16).ctypes.data,
+                                             np.arange(2, dtype=np.uint32).ctypes.data, 2, nodes.ctypes.data, C.byref(cnt), C.byref(depth))
+    assert rc != 0 and b"fp16" in irl.host_lib().mi_host_last_error()
+
+
+def _declared_functions(header: Path):
+    text = re.sub(r"/\*.*?\*/", "", header.read_text(), flags=re.S)
+    return sorted(set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", text)) - {"mi_ray_callback"})
+
+
+def test_device_library_exports_every_declared_symbol():
+    """libmi_raylib.so must load on a box without a GPU and export exactly what include/mi_raylib.h
+    declares; no compute call is made here."""
+    lib = irl.device_lib()
+    names = _declared_functions(ROOT / "include" / "mi_raylib.h")
+    assert {"mi_scene_create", "mi_scene_destroy", "mi_render", "mi_render_device", "mi_trace_time_secs", "mi_get_counters",
+            "mi_scene_set_nif", "mi_scene_set_hdri_rotation", "mi_scene_set_max_nif_batch", "mi_nif_infer_device",
+            "mi_last_error", "mi_version"} <= set(names)
+    for n in names:
+        assert hasattr(lib, n), f"libmi_raylib.so does not export {n}"
+    assert b"gfx950" in lib.mi_version()
+    hl = irl.host_lib()
+    for n in _declared_functions(ROOT / "include" / "mi_scene_host.h"):
+        assert hasattr(hl, n), f"libmi_scene_host.so does not export {n}"
+
+
+def test_device_library_fails_loudly_without_gpu_or_on_bad_input():
+    import torch
+    s = irl.HostScene.builtin("box-simple")
+    if not torch.cuda.is_available():
+        with pytest.raises(irl.RaylibError):
+            irl.IpuScene(s.desc)                                   # no silent CPU fallback
+    h = C.c_void_p()
+    assert irl.device_lib().mi_scene_create(None, C.byref(h)) == 1  # MI_ERR_INVALID_ARG
+    assert b"null" in irl.device_lib().mi_last_error()
+
+
+def test_product_does_not_reach_into_the_oracle():
+    """The oracle is a checker: nothing under ipu_ray_lib_amd/ may mention it."""
+    for p in (ROOT / "ipu_ray_lib_amd").rglob("*"):
+        if p.suffix in {".py", ".h", ".hpp", ".hip", ".cpp"}:
+            txt = p.read_text()
+            assert "ray_oracle" not in txt and "oracle_lib" not in txt and "libray_oracle" not in txt, p
