@@ -142,6 +142,7 @@ def device_lib() -> C.CDLL:
         lib.mi_trace_time_secs.restype = C.c_double
         lib.mi_get_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         lib.mi_reset_counters.argtypes = [C.c_void_p]
+        lib.mi_get_phase_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         lib.mi_scene_set_nif.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_int32]
         lib.mi_scene_set_hdri_rotation.argtypes = [C.c_void_p, C.c_float]
@@ -297,6 +298,12 @@ class IpuScene:
         c = (C.c_uint64 * 4)()
         _check_dev(self._lib.mi_get_counters(self._h, c))
         return {"casts": c[0], "nodes_visited": c[1], "leaf_tests": c[2], "paths": c[3]}
+
+    def phase_stats(self) -> dict:
+        c = (C.c_uint64 * 8)()
+        _check_dev(self._lib.mi_get_phase_stats(self._h, c))
+        names = ("node", "leaf", "shade", "gen")
+        return {n: {"iters": c[2 * i], "lanes": c[2 * i + 1]} for i, n in enumerate(names)}
 
     def reset_counters(self):
         _check_dev(self._lib.mi_reset_counters(self._h))

@@ -2,6 +2,7 @@
 // kernel launches, counters, timing. This file is the whole device library (libmi_raylib.so).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -13,6 +14,7 @@
 #include "../../include/mi_raylib.h"
 #include "ray_math.h"
 #include "trace_kernels.hpp"
+#include "trace_wavefront.hpp"
 #include "nif_kernels.hpp"
 
 using namespace mi;
@@ -75,6 +77,7 @@ struct mi_scene {
   DeviceScene ds{};
   std::vector<void*> allocations;
   unsigned long long* d_counters = nullptr;
+  uint32_t* d_workCounter = nullptr;
   double traceTimeSecs = 0.0;
   float hdriRotationDegrees = 0.f;
   size_t maxNifBatch = 0;
@@ -163,15 +166,15 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
           const mi_vec3& p = d.mesh_verts[mi_.first_vertex + d.mesh_tris[base + k]];
           L.f[3 * k] = p.x; L.f[3 * k + 1] = p.y; L.f[3 * k + 2] = p.z;
         }
-        L.type = LEAF_TRI; L.primID = n.prim_or_second_child; L.triBase = (uint32_t)base;
+        L.type = LEAF_TRI | ((uint32_t)n.geom_id << 16); L.primID = n.prim_or_second_child; L.triBase = (uint32_t)base;
       } else if (r.type == 1) {
         const mi_sphere& s = d.spheres[r.index];
         L.f[0] = s.x; L.f[1] = s.y; L.f[2] = s.z; L.f[3] = s.radius; L.f[4] = s.radius * s.radius;   // Primitives.hpp:44
-        L.type = LEAF_SPHERE; L.primID = 0;                                                           // Primitives.cpp:45
+        L.type = LEAF_SPHERE | ((uint32_t)n.geom_id << 16); L.primID = 0;                                                           // Primitives.cpp:45
       } else {
         const mi_disc& c = d.discs[r.index];
         L.f[0] = c.nx; L.f[1] = c.ny; L.f[2] = c.nz; L.f[3] = c.cx; L.f[4] = c.cy; L.f[5] = c.cz; L.f[6] = c.r * c.r;
-        L.type = LEAF_DISC; L.primID = 0;
+        L.type = LEAF_DISC | ((uint32_t)n.geom_id << 16); L.primID = 0;
       }
       g.link = (uint32_t)leaves.size();
       leaves.push_back(L);
@@ -199,10 +202,12 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
   ds.maxPathLength = d.max_path_length; ds.rouletteStartDepth = d.roulette_start_depth;
   ds.samplesPerPixel = d.samples_per_pixel;
   ds.rngSeed = d.rng_seed;
-  HIP_CHECK(hipMalloc(&S.d_counters, 4 * sizeof(unsigned long long)));
+  HIP_CHECK(hipMalloc(&S.d_counters, 16 * sizeof(unsigned long long)));
   S.keep(S.d_counters);
-  HIP_CHECK(hipMemset(S.d_counters, 0, 4 * sizeof(unsigned long long)));
+  HIP_CHECK(hipMemset(S.d_counters, 0, 16 * sizeof(unsigned long long)));
   ds.counters = S.d_counters;
+  HIP_CHECK(hipMalloc(&S.d_workCounter, sizeof(uint32_t)));
+  S.keep(S.d_workCounter);
 }
 
 void ensureScratch(mi_scene& S, size_t n) {
@@ -220,6 +225,28 @@ void ensureScratch(mi_scene& S, size_t n) {
 }
 
 bool g_fullStats = false;
+WaveTune g_tune = {4, 4, 4};
+int g_kernelChoice = 2;           // 0 = nested-loop kernel, 1 = wavefront (global nodes), 2 = wavefront + LDS-staged nodes
+
+constexpr uint32_t kLdsBudgetBytes = 160 * 1024 - 1024;     // 160 KiB per CU minus the static allocations
+
+template <bool STATS>
+void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStream_t stream) {
+  HIP_CHECK(hipMemsetAsync(S.d_workCounter, 0, sizeof(uint32_t), stream));
+  if (g_kernelChoice == 2 && S.ds.numNodes > 0) {
+    // one 1024-thread workgroup per CU shares one LDS copy of the first nodes of the (preorder) array
+    const uint32_t ldsNodes = std::min<uint32_t>(S.ds.numNodes, kLdsBudgetBytes / (uint32_t)sizeof(GNode));
+    const size_t ldsBytes = (size_t)ldsNodes * sizeof(GNode);
+    auto kern = path_trace_wavefront_kernel<STATS, true, 1024>;
+    static bool attrSet = false;
+    if (!attrSet) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes)); attrSet = true; }
+    const uint32_t blocks = std::min<uint32_t>((cnt + 1023) / 1024, 256);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), ldsBytes, stream, S.ds, d_rays, cnt, S.d_workCounter, ldsNodes, g_tune);
+  } else {
+    const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, S.d_workCounter, 0u, g_tune);
+  }
+}
 
 void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipStream_t stream) {
   if (n == 0) return;
@@ -231,7 +258,11 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
     if (g_fullStats) hipLaunchKernelGGL(shadow_trace_kernel<true>, grid, block, 0, stream, S.ds, d_rays, cnt, .05f, light);
     else hipLaunchKernelGGL(shadow_trace_kernel<false>, grid, block, 0, stream, S.ds, d_rays, cnt, .05f, light);
   } else if (mode == MI_MODE_PATH_TRACE) {
-    if (!S.nif.loaded()) {
+    if (!S.nif.loaded() && g_kernelChoice != 0 && S.ds.samplesPerPixel >= 1 && S.ds.maxPathLength >= 1) {
+      // sample loop inside the kernel (src/IpuScene.cpp:441), phase-scheduled persistent form
+      if (g_fullStats) launchWavefront<true>(S, d_rays, cnt, stream);
+      else launchWavefront<false>(S, d_rays, cnt, stream);
+    } else if (!S.nif.loaded()) {
       // sample loop inside the kernel (src/IpuScene.cpp:441: vertexSampleCount = samplesPerPixel)
       if (g_fullStats) hipLaunchKernelGGL(path_trace_kernel<true>, grid, block, 0, stream, S.ds, d_rays, cnt, 0u, S.ds.samplesPerPixel, (Rng*)nullptr);
       else hipLaunchKernelGGL(path_trace_kernel<false>, grid, block, 0, stream, S.ds, d_rays, cnt, 0u, S.ds.samplesPerPixel, (Rng*)nullptr);
@@ -278,6 +309,8 @@ int mi_scene_create(const mi_scene_desc* desc, mi_scene** out) {
     S->params.mesh_normals = nullptr; S->params.mat_ids = nullptr; S->params.materials = nullptr; S->params.bvh_nodes = nullptr;
     S->params.spheres = nullptr; S->params.discs = nullptr;
     if (const char* e = getenv("MI_RAYLIB_FULL_STATS")) g_fullStats = (e[0] == '1');
+    if (const char* e = getenv("MI_RAYLIB_TUNE")) { unsigned a, b, c; if (sscanf(e, "%u,%u,%u", &a, &b, &c) == 3) g_tune = {a, b, c}; }
+    if (const char* e = getenv("MI_RAYLIB_KERNEL")) g_kernelChoice = (e[0] == '0') ? 0 : (e[0] == '1') ? 1 : 2;
   });
   if (rc != MI_OK) { delete S; return rc; }
   *out = S;
@@ -327,12 +360,23 @@ int mi_get_counters(mi_scene* scene, uint64_t counts[4]) {
   });
 }
 
+int mi_get_phase_stats(mi_scene* scene, uint64_t stats[8]) {
+  if (!scene || !stats) { g_err = "mi_get_phase_stats: null argument"; return MI_ERR_INVALID_ARG; }
+  return guarded([&] {
+    HIP_CHECK(hipSetDevice(scene->device));
+    HIP_CHECK(hipDeviceSynchronize());
+    unsigned long long h[16];
+    HIP_CHECK(hipMemcpy(h, scene->d_counters, sizeof h, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; ++i) stats[i] = h[4 + i];
+  });
+}
+
 int mi_reset_counters(mi_scene* scene) {
   if (!scene) { g_err = "mi_reset_counters: null argument"; return MI_ERR_INVALID_ARG; }
   return guarded([&] {
     HIP_CHECK(hipSetDevice(scene->device));
     HIP_CHECK(hipDeviceSynchronize());
-    HIP_CHECK(hipMemset(scene->d_counters, 0, 4 * sizeof(unsigned long long)));
+    HIP_CHECK(hipMemset(scene->d_counters, 0, 16 * sizeof(unsigned long long)));
   });
 }
 

@@ -32,11 +32,13 @@ enum : uint32_t { LEAF_TRI = 0, LEAF_SPHERE = 1, LEAF_DISC = 2 };
 
 struct __attribute__((aligned(16))) GLeaf {       // 48 B pre-resolved primitive
   float f[9];        // tri: p0,p1,p2 | sphere: cx,cy,cz,radius,radius2 | disc: nx,ny,nz,cx,cy,cz,r2
-  uint32_t type;     // LEAF_*
+  uint32_t type;     // LEAF_* in bits 0..15, geomID in bits 16..31
   uint32_t primID;   // value reported in the hit record
   uint32_t triBase;  // tri: index of the triangle's first u16 in meshTris (for vertex normals)
 };
 static_assert(sizeof(GLeaf) == 48, "GLeaf must stay 48 bytes");
+__host__ __device__ __forceinline__ uint32_t leaf_kind(const GLeaf& L) { return L.type & 0xFFFFu; }
+__host__ __device__ __forceinline__ uint32_t leaf_geom(const GLeaf& L) { return L.type >> 16; }
 
 struct DeviceScene {
   const GNode* nodes;        uint32_t numNodes;
@@ -199,10 +201,10 @@ __device__ __forceinline__ bool traverse(const DeviceScene& sc, f3 o, f3 d, floa
       const GLeaf L = sc.leaves[nd.link];
       float t, b0 = 0.f, b1 = 0.f, b2 = 0.f;
       bool cand;
-      if (L.type == LEAF_TRI) {
+      if (leaf_kind(L) == LEAF_TRI) {
         t = intersect_triangle(mk(L.f[0], L.f[1], L.f[2]), mk(L.f[3], L.f[4], L.f[5]), mk(L.f[6], L.f[7], L.f[8]), o, sh, b0, b1, b2);
         cand = t > 0.f && t < kInf;                 // Mesh.hpp:93
-      } else if (L.type == LEAF_SPHERE) {
+      } else if (leaf_kind(L) == LEAF_SPHERE) {
         t = intersect_sphere(L, o, d, tMin);
         cand = true;                                // Failed() carries t = 0, rejected by t > tMin below
       } else {
@@ -224,7 +226,7 @@ __device__ __forceinline__ bool traverse(const DeviceScene& sc, f3 o, f3 d, floa
 // advanced ray origin (Render.hpp:21-22).
 __device__ __forceinline__ f3 hit_normal(const DeviceScene& sc, const Hit& h, f3 hp) {
   const GLeaf L = sc.leaves[h.leaf];
-  if (L.type == LEAF_TRI) {
+  if (leaf_kind(L) == LEAF_TRI) {
     if (!sc.hasNormals) {
       const f3 p0 = mk(L.f[0], L.f[1], L.f[2]), p1 = mk(L.f[3], L.f[4], L.f[5]), p2 = mk(L.f[6], L.f[7], L.f[8]);
       return normalized(cross(p1 - p0, p2 - p0));
@@ -235,7 +237,7 @@ __device__ __forceinline__ f3 hit_normal(const DeviceScene& sc, const Hit& h, f3
     const mi_vec3 c = sc.meshNormals[fv + sc.meshTris[L.triBase + 2]];
     return normalized((mk(a.x, a.y, a.z) * h.b0) + (mk(b.x, b.y, b.z) * h.b1) + (mk(c.x, c.y, c.z) * h.b2));
   }
-  if (L.type == LEAF_SPHERE) return normalized(hp - mk(L.f[0], L.f[1], L.f[2]));
+  if (leaf_kind(L) == LEAF_SPHERE) return normalized(hp - mk(L.f[0], L.f[1], L.f[2]));
   return mk(L.f[0], L.f[1], L.f[2]);
 }
 

@@ -83,8 +83,12 @@ def test_traversal_visits_exactly_the_reference_nodes(scenes, monkeypatch):
 # ------------------------------------------------------------------------------------------------------
 # path trace: rgb sums + last-sample hit records, per-pixel RNG streams
 # ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kernel", ["0", "1", "2"])
 @pytest.mark.parametrize("name,size,spp", [("box-simple", 128, 32), ("box", 160, 24), ("spheres", 128, 32)])
-def test_path_trace_bit_exact(scenes, name, size, spp):
+def test_path_trace_bit_exact(scenes, name, size, spp, kernel, monkeypatch):
+    """kernel 0 = nested-loop kernel, 1 = phase-scheduled persistent kernel, 2 = the same with the BVH
+    prefix staged in LDS (the default). All three must reproduce the oracle bit for bit."""
+    monkeypatch.setenv("MI_RAYLIB_KERNEL", kernel)
     s = scenes[name]
     s.desc.set_image(size, size)
     s.desc.path_trace = 1
@@ -99,6 +103,8 @@ def test_path_trace_bit_exact(scenes, name, size, spp):
     assert np.isfinite(rgb).all()
     assert rgb.sum() > 0 or name == "spheres"        # 'spheres' has no emitter: it is lit by the NIF environment only
     dev.close()
+    monkeypatch.setenv("MI_RAYLIB_KERNEL", "2")
+    irl.IpuScene(s.desc).close()                      # back to the default kernel for the other tests
 
 
 @pytest.mark.parametrize("maxlen,roulette,aa,seed", [(1, 3, 0.25, 1442), (3, 0, 0.0, 7), (10, 1, 1.5, 2**40 + 3), (0, 3, 0.25, 1)])
