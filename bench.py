@@ -30,21 +30,13 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-TILE_ROWS = 16                  # image rows per shard tile (multi-GPU)
+PMC_SUMMARY = ROOT / "profiles" / "r01_pmc_hbm_summary.json"   # HBM bytes per launch from the committed rocprofv3 --pmc passes
 
 
 def image_shape(n_gpus: int, base: int):
     """Weak scaling: N x base^2 pixels. 1:1x1, 2:2x1, 4:2x2, 8:4x2 (width x height multiples)."""
     kx, ky = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}.get(n_gpus, (n_gpus, 1))
     return base * kx, base * ky
-
-
-def rank_pixels(width: int, height: int, rank: int, world: int):
-    """(row, col) of every pixel this rank owns: row tiles dealt round-robin."""
-    rows = np.arange(height)
-    mine = rows[(rows // TILE_ROWS) % world == rank]
-    rr, cc = np.meshgrid(mine, np.arange(width), indexing="ij")
-    return rr.reshape(-1), cc.reshape(-1)
 
 
 def make_stream(irl, scene, rows, cols):
@@ -103,18 +95,23 @@ def main():
     d.device = local_rank
     dev = irl.IpuScene(d)
 
-    rows, cols = rank_pixels(width, height, rank, world)
+    from ipu_ray_lib_amd import sharding
+    rows, cols = sharding.rank_pixels(width, height, rank, world)
     host_rays = make_stream(irl, scene, rows, cols)
     n = host_rays.size
     d_rays = torch.from_numpy(host_rays.view(np.uint8).reshape(n, irl.TRACE_RESULT.itemsize).copy()).cuda()
     stream = torch.cuda.current_stream()
 
-    def frame():
-        dev.run_device(d_rays.data_ptr(), n, irl.MODE_PATH_TRACE, stream.cuda_stream)
+    def gather():
+        # the ONE collective of a frame: every rank's rgb tiles to rank 0 over RCCL/xGMI
         if dist is not None:
             rgb = d_rays.view(torch.float32).view(n, 21)[:, 0:3].contiguous()
-            gl = [torch.empty_like(rgb) for _ in range(world)] if rank == 0 else None
-            dist.gather(rgb, gl, dst=0)
+            return sharding.gather_frame(dist, rgb, width, height)
+        return None
+
+    def frame():
+        dev.run_device(d_rays.data_ptr(), n, irl.MODE_PATH_TRACE, stream.cuda_stream)
+        gather()
 
     def barrier():
         if dist is not None:
@@ -132,10 +129,7 @@ def main():
         ev[s][0].record(stream)
         dev.run_device(d_rays.data_ptr(), n, irl.MODE_PATH_TRACE, stream.cuda_stream)
         ev[s][1].record(stream)
-        if dist is not None:
-            rgb = d_rays.view(torch.float32).view(n, 21)[:, 0:3].contiguous()
-            gl = [torch.empty_like(rgb) for _ in range(world)] if rank == 0 else None
-            dist.gather(rgb, gl, dst=0)
+        gather()
     barrier()
     elapsed = time.perf_counter() - t0
     counters = dev.counters()
@@ -176,6 +170,13 @@ def main():
     alg_bytes_launch = casts_per_launch * bytes_per_cast + paths_per_launch / args.spp * 168.0
     avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) * 1e-3 if kernel_ms else float("nan")
     achieved_gbs = alg_bytes_launch / avg_kernel_s / 1e9
+    traffic = None
+    if PMC_SUMMARY.exists():
+        # measured by rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes on this same command
+        # (profiles/), corrected as MI355X_MICROARCH.md prescribes; only valid for the profiled workload
+        pm = json.loads(PMC_SUMMARY.read_text())
+        if pm.get("workload") == [args.scene, width, height, args.spp, world]:
+            traffic = pm.get("hbm_bytes_per_launch")
 
     out = {
         "metric": "rays/sec (ray casts/s: CompactBvh intersect+occluded calls, whole node), built-in scene 1440x1440 path-trace",
@@ -197,19 +198,30 @@ def main():
         "ms_per_frame": elapsed / max(args.steps, 1) * 1e3,
         "casts_per_path": total_casts / max(total_paths, 1.0),
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "path_trace_kernel", "avg_launch_ms": avg_kernel_s * 1e3,
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "path_trace_wavefront_kernel", "avg_launch_ms": avg_kernel_s * 1e3,
                      "bytes_per_cast": bytes_per_cast, "nodes_per_cast": nodes_per_cast, "leaf_tests_per_cast": leaf_per_cast},
     }
 
     if not args.no_cpu_baseline and world == 1:
         import oracle_lib
-        cores = os.cpu_count() or 1
-        step_px = 12
-        rr, cc = np.meshgrid(np.arange(0, height, step_px), np.arange(0, width, step_px), indexing="ij")
-        cpu_rays = make_stream(irl, scene, rr.reshape(-1), cc.reshape(-1))
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        cores = max(1, min(cores, 16))            # the GPU box grants 16 host cores per GPU
         cpu_desc = irl.SceneDesc.from_buffer_copy(d)
         cpu_desc.samples_per_pixel = min(args.spp, 250)
+        # calibrate on a coarse pixel grid, then size the sample for about 15 s of CPU work
+        rr, cc = np.meshgrid(np.arange(0, height, 48), np.arange(0, width, 48), indexing="ij")
+        cal = make_stream(irl, scene, rr.reshape(-1), cc.reshape(-1))
+        tc = time.perf_counter()
+        oracle_lib.path_trace_pixel_rng(cpu_desc, cal, cores)
+        cal_s = max(time.perf_counter() - tc, 1e-3)
+        want_px = cal.size * 15.0 / cal_s
+        step_px = int(min(48, max(2, round((width * height / want_px) ** 0.5))))
+        rr, cc = np.meshgrid(np.arange(0, height, step_px), np.arange(0, width, step_px), indexing="ij")
+        cpu_rays = make_stream(irl, scene, rr.reshape(-1), cc.reshape(-1))
         tc = time.perf_counter()
         st = oracle_lib.path_trace_pixel_rng(cpu_desc, cpu_rays, cores)
         cpu_s = time.perf_counter() - tc

@@ -1,0 +1,49 @@
+"""Ray-tile sharding for multi-GPU renders.
+
+Rays are the only sharded dimension; the scene is replicated on every GPU (as the reference replicates
+it on every IPU, src/IpuScene.cpp:473-483, and deals ray batches round-robin over replicas, :676-684).
+Here the shard unit is a tile of TILE_ROWS image rows, dealt round-robin to the ranks, which balances
+the cheap (walls) and expensive (glass, monkey) parts of the frame. There is no exchange while a frame
+renders; at frame end rank 0 collects the tiles with ONE gather (RCCL when the backend is nccl).
+Because every pixel owns its RNG stream, the assembled image is bit-identical for any rank count.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+TILE_ROWS = 16
+
+
+def rank_pixels(width: int, height: int, rank: int, world: int, tile_rows: int = TILE_ROWS):
+    """(rows, cols) of the pixels rank `rank` renders, in the order they appear in its ray stream."""
+    rows = np.arange(height)
+    mine = rows[(rows // tile_rows) % world == rank]
+    rr, cc = np.meshgrid(mine, np.arange(width), indexing="ij")
+    return rr.reshape(-1), cc.reshape(-1)
+
+
+def padded_count(width: int, height: int, world: int, tile_rows: int = TILE_ROWS) -> int:
+    """Largest per-rank pixel count: gather needs equal-sized contributions, short ranks pad."""
+    return max(rank_pixels(width, height, r, world, tile_rows)[0].size for r in range(world))
+
+
+def gather_frame(dist, rgb, width: int, height: int, tile_rows: int = TILE_ROWS):
+    """One collective per frame. `rgb`: this rank's [n_r, 3] float32 torch tensor (any device the
+    process group supports). Returns the [height, width, 3] frame on rank 0, None elsewhere."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n_pad = padded_count(width, height, world, tile_rows)
+    send = rgb
+    if rgb.shape[0] != n_pad:
+        send = torch.zeros(n_pad, 3, dtype=rgb.dtype, device=rgb.device)
+        send[: rgb.shape[0]] = rgb
+    bufs = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+    dist.gather(send, bufs, dst=0)
+    if rank != 0:
+        return None
+    frame = torch.zeros(height, width, 3, dtype=rgb.dtype, device=rgb.device)
+    for r in range(world):
+        rows, cols = rank_pixels(width, height, r, world, tile_rows)
+        idx = torch.from_numpy(rows * width + cols).to(rgb.device)
+        frame.view(-1, 3)[idx] = bufs[r][: rows.size]
+    return frame
