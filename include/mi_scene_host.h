@@ -22,10 +22,16 @@ extern "C" {
 
 typedef struct mi_host_scene mi_host_scene;   /* opaque; owns every array a desc points into */
 
-/* Built-in scenes of the reference CLI (--scene box-simple | box | spheres, trace.cpp:357).
+/* Built-in scenes of the reference CLI (--scene box-simple | box | spheres, trace.cpp:357),
+ * plus "monkey": the monkey bust alone in an open environment (BASELINE config 5).
  * `mesh_file` is the glTF-binary mesh placed on the short block for "box"
  * (assets/monkey_bust.glb in the reference, src/app_utils.cpp:264); ignored otherwise. */
 int mi_host_scene_builtin(const char* scene_name, const char* mesh_file, mi_host_scene** out);
+
+/* importScene(filename, loadNormals) (src/scene_utils.cpp:152-317, --mesh-file/--load-normals): a
+ * complete scene with camera and materials from a Collada (.dae) file, camera moved to the origin,
+ * materials re-interpreted with the reference's heuristics. */
+int mi_host_scene_import(const char* file, int load_normals, mi_host_scene** out);
 
 /* Build a scene from caller-provided arrays (same array contract as mi_scene_desc, but
  * bvh_nodes/max_leaf_depth are ignored and rebuilt). Used by tests with synthetic geometry. */

@@ -106,6 +106,7 @@ def host_lib() -> C.CDLL:
         lib = _load(PKG_DIR / "libmi_scene_host.so")
         lib.mi_host_last_error.restype = C.c_char_p
         lib.mi_host_scene_builtin.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+        lib.mi_host_scene_import.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
         lib.mi_host_scene_from_arrays.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
         lib.mi_host_scene_fill_desc.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
         lib.mi_host_scene_destroy.argtypes = [C.c_void_p]
@@ -176,6 +177,13 @@ class HostScene:
         mesh = str(mesh_file if mesh_file is not None else DEFAULT_MESH)
         h = C.c_void_p()
         _check_host(host_lib().mi_host_scene_builtin(name.encode(), mesh.encode(), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def import_file(cls, path, load_normals: bool = False) -> "HostScene":
+        """importScene(): --mesh-file / --load-normals of the reference CLI."""
+        h = C.c_void_p()
+        _check_host(host_lib().mi_host_scene_import(str(path).encode(), 1 if load_normals else 0, C.byref(h)))
         return cls(h)
 
     @classmethod

@@ -36,7 +36,23 @@ int mi_host_scene_builtin(const char* scene_name, const char* mesh_file, mi_host
     SceneDescription desc;
     if (name == "box-simple" || name == "box") desc = makeCornellBoxScene(mesh_file ? mesh_file : "", name == "box-simple");
     else if (name == "spheres") desc = makePrimitiveScene();
+    else if (name == "monkey") desc = makeMonkeyScene(mesh_file ? mesh_file : "");
     else throw std::invalid_argument("Invalid scene selection: '" + name + "'");   // src/app_utils.cpp:268-270
+    auto* hs = new mi_host_scene;
+    hs->packed = packScene(desc);
+    *out = hs;
+  });
+}
+
+int mi_host_scene_import(const char* file, int load_normals, mi_host_scene** out) {
+  if (!file || !out) { g_err = "null argument"; return MI_ERR_INVALID_ARG; }
+  return guarded([&] {
+    const std::string path(file);
+    const std::string ext = path.size() >= 4 ? path.substr(path.size() - 4) : "";
+    SceneDescription desc;
+    if (ext == ".dae" || ext == ".DAE") desc = importColladaScene(path, load_normals != 0);
+    else if (ext == ".glb") { loadGlbMeshes(path, false); throw std::runtime_error("No camera found in scene file."); }   // scene_utils.cpp:177-180
+    else throw std::runtime_error("Could not load scene file.");
     auto* hs = new mi_host_scene;
     hs->packed = packScene(desc);
     *out = hs;

@@ -150,6 +150,23 @@ SceneDescription makePrimitiveScene() {
   return s;
 }
 
+// BASELINE config 5 names `assets/monkey_bust.glb` + the NIF environment. The reference cannot load
+// that file as a scene (it has no camera, scene_utils.cpp:177-180), so the scene is defined here: the
+// bust placed exactly as importMesh places it in the box scene (scene_utils.cpp:122-143), seen from the
+// Cornell camera, with NO box around it: every path ends in the environment. Both meshes are white diffuse.
+SceneDescription makeMonkeyScene(const std::string& meshFile) {
+  if (meshFile.empty()) throw std::runtime_error("scene 'monkey' needs the monkey-bust mesh file (assets/monkey_bust.glb)");
+  SceneDescription s;
+  for (auto& m : loadGlbMeshes(meshFile, /*loadNormals=*/false)) { placeImportedMesh(m); s.meshes.push_back(std::move(m)); }
+  const f3 cam = mk(278.f, 273.f, -800.f);
+  for (auto& m : s.meshes)
+    for (auto& v : m.vertices) { v = v - cam; v.x = -v.x; v.z = -v.z; }
+  s.materials = {material(mk(.75f, .75f, .75f), mk(0, 0, 0), 0)};
+  s.matIDs.assign(s.meshes.size(), 0u);
+  s.horizontalFov = (float)(3.14159265358979323846264338327950288 / 4.0);
+  return s;
+}
+
 // buildSceneData (src/app_utils.cpp:291-371) + makeBuildPrimitivesForEmbree (:145-188)
 PackedScene packScene(const SceneDescription& scene) {
   PackedScene d;

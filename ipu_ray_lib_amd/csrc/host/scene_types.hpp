@@ -65,6 +65,10 @@ std::vector<TriMesh> loadGlbMeshes(const std::string& path, bool loadNormals);
 // scene_builtin.cpp
 SceneDescription makeCornellBoxScene(const std::string& meshFile, bool boxOnly);
 SceneDescription makePrimitiveScene();
+SceneDescription makeMonkeyScene(const std::string& meshFile);   // monkey bust in an open environment (BASELINE config 5)
+
+// dae_reader.cpp: importScene() for Collada files
+SceneDescription importColladaScene(const std::string& path, bool loadNormals);
 PackedScene packScene(const SceneDescription& scene);
 
 const float* sinTable();   // 92-entry table for sincos_deg_table on the host

@@ -41,7 +41,8 @@ const char* kHelp =
     "  -h [ --height ] arg (=432)          Set rendered image height.\n"
     "  --crop arg                          Window of the image to render: wxh+c+r.\n"
     "  --anti-alias arg (=0.25)            Width of anti-aliasing noise distribution in pixels.\n"
-    "  --mesh-file arg                     Mesh file for the built-in box scene (glTF binary). Default: assets/monkey_bust.glb.\n"
+    "  --mesh-file arg                     A Collada (.dae) scene with camera to render instead of a built-in scene, or the\n"
+    "                                      glTF-binary mesh placed in the built-in box scene (default assets/monkey_bust.glb).\n"
     "  --nif-hdri arg                      Path to the 'assets.extra' directory of a NIF model (nif_metadata.txt + nif_weights.bin).\n"
     "  --hdri-rotation arg (=0)            Azimuthal rotation for HDRI environment map (degrees).\n"
     "  --load-normals                      Load (and interpolate) vertex normals of a mesh file.\n"
@@ -215,7 +216,10 @@ int main(int argc, char** argv) {
   mi_host_scene* host = nullptr;
   std::string mesh = args.meshFile;
   if (mesh.empty()) mesh = "assets/monkey_bust.glb";
-  if (mi_host_scene_builtin(args.scene.c_str(), mesh.c_str(), &host) != MI_OK) {
+  const bool importWholeScene = args.meshFile.size() > 4 && args.meshFile.substr(args.meshFile.size() - 4) == ".dae";
+  const int rcScene = importWholeScene ? mi_host_scene_import(args.meshFile.c_str(), args.loadNormals ? 1 : 0, &host)   // importScene, app_utils.cpp:274-275
+                                       : mi_host_scene_builtin(args.scene.c_str(), mesh.c_str(), &host);
+  if (rcScene != MI_OK) {
     std::fprintf(stderr, "[error] %s\n", mi_host_last_error());
     return EXIT_FAILURE;
   }

@@ -244,6 +244,26 @@ def test_random_soup_with_and_without_vertex_normals(with_normals):
     dev.close()
 
 
+def test_config3_collada_scene_with_vertex_normals():
+    """BASELINE config 3 (assets/test_scene.dae --load-normals) at reduced size/spp: every TraceResult byte."""
+    from pathlib import Path
+    s = irl.HostScene.import_file(Path(irl.REPO_ROOT) / "assets" / "test_scene.dae", load_normals=True)
+    d = s.desc
+    d.set_image(240, 240); d.samples_per_pixel = 12
+    dev = irl.IpuScene(d)
+    got = s.init_ray_stream(); want = got.copy()
+    dev.run(got, irl.MODE_SHADOW_TRACE); ol.shadow_trace(d, want, 16)
+    assert_streams_identical(got, want, "test_scene.dae shadow trace")
+    dev.reset_counters()
+    got = s.init_ray_stream(); want = got.copy()
+    dev.run(got, irl.MODE_PATH_TRACE); st = ol.path_trace_pixel_rng(d, want, 16)
+    assert_streams_identical(got, want, "test_scene.dae path trace")
+    assert dev.counters()["casts"] == st.casts
+    rgb = np.stack([got["rgb"][k] for k in "xyz"], 1)
+    assert np.isfinite(rgb).all() and rgb.sum() > 0
+    dev.close()
+
+
 def test_unknown_material_marks_error_in_band():
     """Unknown material type => rgb *= NaN, flags |= ERROR, path continues (codelets :240-244)."""
     rng = np.random.default_rng(99)
@@ -370,6 +390,29 @@ def test_nif_mlp_against_oracle(scenes):
     assert np.isfinite(got).all()
     err = np.abs(got - want) / (np.abs(want) + 1e-3 / 0.02)
     assert np.quantile(err, 0.999) < 0.02 and err.max() < 0.10, (np.quantile(err, 0.999), err.max())
+    dev.close()
+
+
+def test_config5_monkey_with_nif_environment():
+    """BASELINE config 5 scene (monkey bust, open environment, NIF-shaped 6x320 MLP with synthetic weights) at
+    reduced size/spp. Hit records bit exact, rgb within the MLP tolerance."""
+    rng = np.random.default_rng(8)
+    ks, bs, relu = _nif_weights(rng)
+    mean = np.array([-2.3514461517333984, -2.2660605907440186, -1.9648972749710083], np.float32) - np.float32(1e-8)
+    s = irl.HostScene.builtin("monkey")
+    d = s.desc
+    d.set_image(128, 96); d.samples_per_pixel = 4
+    dev = irl.IpuScene(d)
+    dev.setNif(ks, bs, relu, 12, 3.4299468994140625, mean, True)
+    got = s.init_ray_stream(); want = got.copy()
+    dev.run(got, irl.MODE_PATH_TRACE)
+    nif, keep = ol.make_nif(ks, bs, relu, 12, 3.4299468994140625, mean, True, half_features=True, half_weights_acts=True)
+    st = ol.Stats()
+    ol.lib().o_path_trace_nif_pixel_rng(C.byref(d), C.byref(nif), 0.0, want.ctypes.data, want.size, 16, C.byref(st))
+    assert rows_differing(np.ascontiguousarray(got["h"]), np.ascontiguousarray(want["h"])).size == 0
+    g = np.stack([got["rgb"][k] for k in "xyz"], 1); w = np.stack([want["rgb"][k] for k in "xyz"], 1)
+    err = np.abs(g - w) / (np.abs(w) + 0.05)
+    assert np.quantile(err, 0.995) < 0.03 and err.max() < 0.3, (np.quantile(err, 0.995), err.max())
     dev.close()
 
 

@@ -89,6 +89,38 @@ def test_compact_bvh_contract(name):
     assert len(pairs) == expected
 
 
+def test_collada_import_config3_scene():
+    """BASELINE config 3: assets/test_scene.dae --load-normals. SURVEY.md §8d: 10 meshes, 8 474 triangles =>
+    16 947 nodes, 9 materials incl. 2 emissive (shininess 10 / 350 as emission factor), glass by name,
+    reflectivity => specular, camera xfov 45 degrees, everything in front of the camera."""
+    s = irl.HostScene.import_file(ROOT / "assets" / "test_scene.dae", load_normals=True)
+    d = s.desc
+    assert (d.num_meshes, d.num_tris, d.num_nodes, d.num_materials) == (10, 8474, 16947, 9)
+    assert d.num_normals == d.num_verts > 0
+    assert np.float32(d.fov_radians) == np.float32(np.deg2rad(np.float32(45.0)))
+    m = s.materials
+    assert sorted(int(x) for x in m["type"]) == [0, 0, 0, 0, 1, 1, 2, 2, 2]
+    em = m[m["emissive"] == 1]
+    assert len(em) == 2
+    assert np.allclose(sorted(float(e["emission"]["x"]) for e in em), [10.0, 274.26], rtol=1e-3)
+    assert s.verts["z"].max() < 0
+    nl = np.sqrt(sum(np.frombuffer(s._view(d.mesh_normals, d.num_normals, irl.VEC3)[k].tobytes(), np.float32) ** 2 for k in "xyz"))
+    assert np.allclose(nl, 1.0, atol=1e-5)
+    s2 = irl.HostScene.import_file(ROOT / "assets" / "test_scene.dae", load_normals=False)
+    assert s2.desc.num_normals == 0 and s2.desc.num_tris == 8474
+    h = C.c_void_p()
+    assert irl.host_lib().mi_host_scene_import(str(irl.DEFAULT_MESH).encode(), 0, C.byref(h)) != 0
+    assert b"No camera found" in irl.host_lib().mi_host_last_error()       # scene_utils.cpp:177-180
+
+
+def test_monkey_scene_config5():
+    s = irl.HostScene.builtin("monkey")
+    assert (s.desc.num_meshes, s.desc.num_tris, s.desc.num_spheres, s.desc.num_discs) == (2, 4000, 0, 0)
+    box = irl.HostScene.builtin("box")
+    # the bust sits exactly where the box scene has it
+    assert np.array_equal(s.verts.view(np.uint8), box.verts[64:].view(np.uint8))
+
+
 def test_ray_stream_matches_oracle_restatement():
     s = irl.HostScene.builtin("box-simple")
     for (w, h, crop) in [(512, 512, None), (1440, 1440, (37, 19, 700, 300)), (768, 432, None)]:
