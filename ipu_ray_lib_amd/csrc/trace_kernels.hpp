@@ -90,9 +90,11 @@ __device__ __forceinline__ float intersect_triangle(f3 p0, f3 p1, f3 p2, f3 o, c
   if (det == 0) return 0.f;
   p0t.z *= sh.sz; p1t.z *= sh.sz; p2t.z *= sh.sz;
   const float tScaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
-  const float tFar = kInf;
-  if (det < 0.f && (tScaled >= 0.f || tScaled < tFar * det)) return 0.f;
-  else if (det > 0.f && (tScaled <= 0.f || tScaled > tFar * det)) return 0.f;
+  // Mesh.cpp:62-66 with tFar = +inf (Mesh.hpp:90-92): tFar*det is -inf (det<0) / +inf (det>0; det != 0 here),
+  // and "tScaled < -inf" / "tScaled > +inf" are false for every float including NaN, so those two
+  // comparisons drop out exactly.
+  if (det < 0.f && tScaled >= 0.f) return 0.f;
+  else if (det > 0.f && tScaled <= 0.f) return 0.f;
   const float invDet = 1 / det;
   b0 = e0 * invDet; b1 = e1 * invDet; b2 = e2 * invDet;
   const float t = tScaled * invDet;

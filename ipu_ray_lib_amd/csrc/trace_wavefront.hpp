@@ -56,6 +56,7 @@ __global__ void __launch_bounds__(BLOCK) path_trace_wavefront_kernel(DeviceScene
   Shear sh; sh.kz = 2; sh.sx = sh.sy = 0.f; sh.sz = 1.f;
   Hit hit; hit.t = kInf; hit.leaf = 0xFFFFFFFFu; hit.geomID = 0xFFFFu; hit.b0 = hit.b1 = hit.b2 = 0.f;
   uint32_t oFlags = 0, oPrim = MI_INVALID_PRIM, oGeom = MI_INVALID_GEOM;
+  bool exactSlab = false;
   float oTmax = kInf;
   CastStats cs = {0, 0};
   uint32_t casts = 0, paths = 0;
@@ -109,30 +110,28 @@ __global__ void __launch_bounds__(BLOCK) path_trace_wavefront_kernel(DeviceScene
         if (LDS_NODES && node < ldsNodeCount) nd = ldsNodes[node];
         else nd = sc.nodes[node];
         if (STATS) cs.nodes++;
-        float t0 = 0.f, t1 = hit.t;
-        {
-          const float maxx = nd.minx + half_bits_to_float(nd.hx);
-          float tmin = (nd.minx - o.x) * inv.x, tmax = (maxx - o.x) * inv.x;
-          if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; }
-          tmax *= kSlabScale;
-          t0 = tmin > t0 ? tmin : t0;
-          t1 = tmax < t1 ? tmax : t1;
-        }
-        {
-          const float maxy = nd.miny + half_bits_to_float(nd.hy);
-          float tmin = (nd.miny - o.y) * inv.y, tmax = (maxy - o.y) * inv.y;
-          if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; }
-          tmax *= kSlabScale;
-          t0 = tmin > t0 ? tmin : t0;
-          t1 = tmax < t1 ? tmax : t1;
-        }
-        {
-          const float maxz = nd.minz + half_bits_to_float(nd.hz);
-          float tmin = (nd.minz - o.z) * inv.z, tmax = (maxz - o.z) * inv.z;
-          if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; }
-          tmax *= kSlabScale;
-          t0 = tmin > t0 ? tmin : t0;
-          t1 = tmax < t1 ? tmax : t1;
+        // Box test (CompactBVH2Node.cpp:5-22, intersectRaySlab CompactBVH2Node.hpp:14-50).
+        // Fast form: with finite origin and finite inverse direction no slab product can be NaN, and for
+        // non-NaN values the reference's ordered compare/selects ARE min/max: swap(tmin,tmax) = (min,max),
+        // "t0 = tmin > t0 ? tmin : t0" = max, "t1 = tmax < t1 ? tmax : t1" = min, in any axis order; the
+        // sign of a zero never reaches the result (only t0 > t1 is used). Lanes whose ray has a zero /
+        // denormal direction component or a non-finite origin (exactSlab) redo the test with the
+        // reference's literal compare/select sequence below, so NaN cases stay bit-identical too.
+        const float maxx = nd.minx + half_bits_to_float(nd.hx);
+        const float maxy = nd.miny + half_bits_to_float(nd.hy);
+        const float maxz = nd.minz + half_bits_to_float(nd.hz);
+        const float ax = (nd.minx - o.x) * inv.x, bx = (maxx - o.x) * inv.x;
+        const float ay = (nd.miny - o.y) * inv.y, by = (maxy - o.y) * inv.y;
+        const float az = (nd.minz - o.z) * inv.z, bz = (maxz - o.z) * inv.z;
+        float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
+        float t1 = fminf(fminf(fmaxf(ax, bx) * kSlabScale, fmaxf(ay, by) * kSlabScale), fminf(fmaxf(az, bz) * kSlabScale, hit.t));
+        if (__ballot(exactSlab)) {
+          if (exactSlab) {
+            t0 = 0.f; t1 = hit.t;
+            { float tmin = ax, tmax = bx; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
+            { float tmin = ay, tmax = by; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
+            { float tmin = az, tmax = bz; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
+          }
         }
         const bool boxHit = !(t0 > t1);
         const bool isLeaf = nd.geomID != 0xFFFFu;
@@ -233,6 +232,7 @@ __global__ void __launch_bounds__(BLOCK) path_trace_wavefront_kernel(DeviceScene
           // next bounce: offsetRay + cast set-up (codelets :207-211)
           o = offset_origin(o, d, nrm);
           inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+          exactSlab = !(fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf && fabsf(o.x) < kInf && fabsf(o.y) < kInf && fabsf(o.z) < kInf);
           sh = make_shear(d);
           hit.t = kInf; hit.leaf = 0xFFFFFFFFu;
           node = 0;
@@ -256,6 +256,7 @@ __global__ void __launch_bounds__(BLOCK) path_trace_wavefront_kernel(DeviceScene
         bounce = 0;
         o = offset_origin(o, d, nrm);
         inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+        exactSlab = !(fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf && fabsf(o.x) < kInf && fabsf(o.y) < kInf && fabsf(o.z) < kInf);
         sh = make_shear(d);
         hit.t = kInf; hit.leaf = 0xFFFFFFFFu;
         node = 0;
