@@ -225,8 +225,8 @@ void ensureScratch(mi_scene& S, size_t n) {
 }
 
 bool g_fullStats = false;
-WaveTune g_tune = {4, 4, 4};
-int g_kernelChoice = 2;           // 0 = nested-loop kernel, 1 = wavefront (global nodes), 2 = wavefront + LDS-staged nodes
+WaveTune g_tune = {5, 6, 8, 16, 2};
+int g_kernelChoice = 1;           // 0 = nested-loop kernel, 1 = wavefront (global nodes), 2 = wavefront + LDS-staged nodes
 
 constexpr uint32_t kLdsBudgetBytes = 160 * 1024 - 1024;     // 160 KiB per CU minus the static allocations
 
@@ -309,8 +309,8 @@ int mi_scene_create(const mi_scene_desc* desc, mi_scene** out) {
     S->params.mesh_normals = nullptr; S->params.mat_ids = nullptr; S->params.materials = nullptr; S->params.bvh_nodes = nullptr;
     S->params.spheres = nullptr; S->params.discs = nullptr;
     if (const char* e = getenv("MI_RAYLIB_FULL_STATS")) g_fullStats = (e[0] == '1');
-    if (const char* e = getenv("MI_RAYLIB_TUNE")) { unsigned a, b, c; if (sscanf(e, "%u,%u,%u", &a, &b, &c) == 3) g_tune = {a, b, c}; }
-    if (const char* e = getenv("MI_RAYLIB_KERNEL")) g_kernelChoice = (e[0] == '0') ? 0 : (e[0] == '1') ? 1 : 2;
+    if (const char* e = getenv("MI_RAYLIB_TUNE")) { unsigned a, b, c, dd = 16, k8 = 2; if (sscanf(e, "%u,%u,%u,%u,%u", &a, &b, &c, &dd, &k8) >= 3) g_tune = {a, b, c, dd, k8}; }
+    if (const char* e = getenv("MI_RAYLIB_KERNEL")) g_kernelChoice = (e[0] == '0') ? 0 : (e[0] == '2') ? 2 : 1;
   });
   if (rc != MI_OK) { delete S; return rc; }
   *out = S;

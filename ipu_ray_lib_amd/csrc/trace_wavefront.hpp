@@ -25,7 +25,7 @@ enum : uint32_t { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_GEN = 3, PH_FETCH =
 // Scheduling thresholds: a waiting phase runs as soon as this many lanes are parked in it; below the
 // thresholds NODE runs while it has any lane, and when nothing traverses the fullest phase runs.
 // Derivation of the defaults (a batch/occupancy trade-off under the 64-lane budget) is in DESIGN.md §6.
-struct WaveTune { uint32_t leafAt, shadeAt, genAt; };
+struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8; };
 
 template <bool STATS, bool LDS_NODES, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) path_trace_wavefront_kernel(DeviceScene sc, mi_trace_result* rays, uint32_t n,
@@ -104,45 +104,51 @@ __global__ void __launch_bounds__(BLOCK) path_trace_wavefront_kernel(DeviceScene
 
     if (run == 0) {
       // ---------------- NODE: one box test per lane ----------------
-      if (STATS) { itN++; lnN += cN; }
-      if (ph == PH_NODE) {
-        GNode nd;
-        if (LDS_NODES && node < ldsNodeCount) nd = ldsNodes[node];
-        else nd = sc.nodes[node];
-        if (STATS) cs.nodes++;
-        // Box test (CompactBVH2Node.cpp:5-22, intersectRaySlab CompactBVH2Node.hpp:14-50).
-        // Fast form: with finite origin and finite inverse direction no slab product can be NaN, and for
-        // non-NaN values the reference's ordered compare/selects ARE min/max: swap(tmin,tmax) = (min,max),
-        // "t0 = tmin > t0 ? tmin : t0" = max, "t1 = tmax < t1 ? tmax : t1" = min, in any axis order; the
-        // sign of a zero never reaches the result (only t0 > t1 is used). Lanes whose ray has a zero /
-        // denormal direction component or a non-finite origin (exactSlab) redo the test with the
-        // reference's literal compare/select sequence below, so NaN cases stay bit-identical too.
-        const float maxx = nd.minx + half_bits_to_float(nd.hx);
-        const float maxy = nd.miny + half_bits_to_float(nd.hy);
-        const float maxz = nd.minz + half_bits_to_float(nd.hz);
-        const float ax = (nd.minx - o.x) * inv.x, bx = (maxx - o.x) * inv.x;
-        const float ay = (nd.miny - o.y) * inv.y, by = (maxy - o.y) * inv.y;
-        const float az = (nd.minz - o.z) * inv.z, bz = (maxz - o.z) * inv.z;
-        float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
-        float t1 = fminf(fminf(fmaxf(ax, bx) * kSlabScale, fmaxf(ay, by) * kSlabScale), fminf(fmaxf(az, bz) * kSlabScale, hit.t));
-        if (__ballot(exactSlab)) {
-          if (exactSlab) {
-            t0 = 0.f; t1 = hit.t;
-            { float tmin = ax, tmax = bx; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
-            { float tmin = ay, tmax = by; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
-            { float tmin = az, tmax = bz; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
+      // NODE steps run in a short burst: re-voting costs about as much as a box test, so the wave keeps
+      // stepping while at least 3/4 of the lanes that started the burst are still traversing (<= 4 steps).
+      uint32_t stay = cN, burst = 0;
+      do {
+        if (STATS) { itN++; lnN += stay; }
+        if (ph == PH_NODE) {
+          GNode nd;
+          if (LDS_NODES && node < ldsNodeCount) nd = ldsNodes[node];
+          else nd = sc.nodes[node];
+          if (STATS) cs.nodes++;
+          // Box test (CompactBVH2Node.cpp:5-22, intersectRaySlab CompactBVH2Node.hpp:14-50).
+          // Fast form: with finite origin and finite inverse direction no slab product can be NaN, and for
+          // non-NaN values the reference's ordered compare/selects ARE min/max: swap(tmin,tmax) = (min,max),
+          // "t0 = tmin > t0 ? tmin : t0" = max, "t1 = tmax < t1 ? tmax : t1" = min, in any axis order; the
+          // sign of a zero never reaches the result (only t0 > t1 is used). Lanes whose ray has a zero /
+          // denormal direction component or a non-finite origin (exactSlab) redo the test with the
+          // reference's literal compare/select sequence below, so NaN cases stay bit-identical too.
+          const float maxx = nd.minx + half_bits_to_float(nd.hx);
+          const float maxy = nd.miny + half_bits_to_float(nd.hy);
+          const float maxz = nd.minz + half_bits_to_float(nd.hz);
+          const float ax = (nd.minx - o.x) * inv.x, bx = (maxx - o.x) * inv.x;
+          const float ay = (nd.miny - o.y) * inv.y, by = (maxy - o.y) * inv.y;
+          const float az = (nd.minz - o.z) * inv.z, bz = (maxz - o.z) * inv.z;
+          float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
+          float t1 = fminf(fminf(fmaxf(ax, bx) * kSlabScale, fmaxf(ay, by) * kSlabScale), fminf(fmaxf(az, bz) * kSlabScale, hit.t));
+          if (__ballot(exactSlab)) {
+            if (exactSlab) {
+              t0 = 0.f; t1 = hit.t;
+              { float tmin = ax, tmax = bx; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
+              { float tmin = ay, tmax = by; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
+              { float tmin = az, tmax = bz; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
+            }
+          }
+          const bool boxHit = !(t0 > t1);
+          const bool isLeaf = nd.geomID != 0xFFFFu;
+          if (boxHit && isLeaf) {
+            pendLeaf = nd.link;
+            ph = PH_LEAF;
+          } else {
+            node = (boxHit || isLeaf) ? node + 1 : nd.link;
+            if (node >= numNodes) ph = PH_SHADE;
           }
         }
-        const bool boxHit = !(t0 > t1);
-        const bool isLeaf = nd.geomID != 0xFFFFu;
-        if (boxHit && isLeaf) {
-          pendLeaf = nd.link;
-          ph = PH_LEAF;
-        } else {
-          node = (boxHit || isLeaf) ? node + 1 : nd.link;
-          if (node >= numNodes) ph = PH_SHADE;
-        }
-      }
+        stay = (uint32_t)__popcll(__ballot(ph == PH_NODE));
+      } while (++burst < tune.burst && stay * 8u >= cN * tune.keep8 && stay > 0);
     } else if (run == 1) {
       // ---------------- LEAF: one primitive test per lane ----------------
       if (STATS) { itL++; lnL += cL; }

@@ -87,7 +87,7 @@ def test_traversal_visits_exactly_the_reference_nodes(scenes, monkeypatch):
 @pytest.mark.parametrize("name,size,spp", [("box-simple", 128, 32), ("box", 160, 24), ("spheres", 128, 32)])
 def test_path_trace_bit_exact(scenes, name, size, spp, kernel, monkeypatch):
     """kernel 0 = nested-loop kernel, 1 = phase-scheduled persistent kernel, 2 = the same with the BVH
-    prefix staged in LDS (the default). All three must reproduce the oracle bit for bit."""
+    prefix staged in LDS; 1 is the default. All three must reproduce the oracle bit for bit."""
     monkeypatch.setenv("MI_RAYLIB_KERNEL", kernel)
     s = scenes[name]
     s.desc.set_image(size, size)
@@ -103,7 +103,7 @@ def test_path_trace_bit_exact(scenes, name, size, spp, kernel, monkeypatch):
     assert np.isfinite(rgb).all()
     assert rgb.sum() > 0 or name == "spheres"        # 'spheres' has no emitter: it is lit by the NIF environment only
     dev.close()
-    monkeypatch.setenv("MI_RAYLIB_KERNEL", "2")
+    monkeypatch.setenv("MI_RAYLIB_KERNEL", "1")
     irl.IpuScene(s.desc).close()                      # back to the default kernel for the other tests
 
 
