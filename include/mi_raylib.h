@@ -156,9 +156,10 @@ int mi_reset_counters(mi_scene* scene);
 /* Diagnostics of the phase-scheduled path-trace kernel (only filled when the instrumented kernel
  * variant is selected with MI_RAYLIB_FULL_STATS=1): for each phase NODE, LEAF, SHADE, GEN the number
  * of wave-level executions and the sum of lanes active in them:
- * stats = {node_iters, node_lanes, leaf_iters, leaf_lanes, shade_iters, shade_lanes, gen_iters, gen_lanes}.
+ * stats[0..7] = {node_iters, node_lanes, leaf_iters, leaf_lanes, shade_iters, shade_lanes, gen_iters, gen_lanes},
+ * stats[8..11] = shader cycles summed over waves spent in {traversal loop, SHADE, GEN, whole kernel loop}.
  * No reference counterpart (the IPU has no SIMT lanes); used by DESIGN.md's occupancy table. */
-int mi_get_phase_stats(mi_scene* scene, uint64_t stats[8]);
+int mi_get_phase_stats(mi_scene* scene, uint64_t stats[12]);
 
 /* Replaces: IpuScene::loadNifModel (src/IpuScene.cpp:174-187) with the weights handed over as
  * arrays (the reference's Keras-H5 file loader is out of scope).

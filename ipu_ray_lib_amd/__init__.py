@@ -308,10 +308,12 @@ class IpuScene:
         return {"casts": c[0], "nodes_visited": c[1], "leaf_tests": c[2], "paths": c[3]}
 
     def phase_stats(self) -> dict:
-        c = (C.c_uint64 * 8)()
+        c = (C.c_uint64 * 12)()
         _check_dev(self._lib.mi_get_phase_stats(self._h, c))
         names = ("node", "leaf", "shade", "gen")
-        return {n: {"iters": c[2 * i], "lanes": c[2 * i + 1]} for i, n in enumerate(names)}
+        out = {n: {"iters": c[2 * i], "lanes": c[2 * i + 1]} for i, n in enumerate(names)}
+        out["cycles"] = {"traverse": c[8], "shade": c[9], "gen": c[10], "total": c[11]}
+        return out
 
     def reset_counters(self):
         _check_dev(self._lib.mi_reset_counters(self._h))

@@ -225,7 +225,7 @@ void ensureScratch(mi_scene& S, size_t n) {
 }
 
 bool g_fullStats = false;
-WaveTune g_tune = {5, 6, 8, 16, 2};
+WaveTune g_tune = {5, 8, 12, 32, 2};
 int g_kernelChoice = 1;           // 0 = nested-loop kernel, 1 = wavefront (global nodes), 2 = wavefront + LDS-staged nodes
 
 constexpr uint32_t kLdsBudgetBytes = 160 * 1024 - 1024;     // 160 KiB per CU minus the static allocations
@@ -237,14 +237,19 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
     // one 1024-thread workgroup per CU shares one LDS copy of the first nodes of the (preorder) array
     const uint32_t ldsNodes = std::min<uint32_t>(S.ds.numNodes, kLdsBudgetBytes / (uint32_t)sizeof(GNode));
     const size_t ldsBytes = (size_t)ldsNodes * sizeof(GNode);
-    auto kern = path_trace_wavefront_kernel<STATS, true, 1024>;
+    auto kern = path_trace_wavefront_kernel<STATS, true, 1024, false>;
     static bool attrSet = false;
     if (!attrSet) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes)); attrSet = true; }
     const uint32_t blocks = std::min<uint32_t>((cnt + 1023) / 1024, 256);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), ldsBytes, stream, S.ds, d_rays, cnt, S.d_workCounter, ldsNodes, g_tune);
+  } else if (g_kernelChoice == 3 && !S.ds.hasNormals) {
+    // two rays per lane, the second parked in LDS: 9 uint4 groups x 64 lanes x 4 waves = 36 KiB per workgroup
+    const size_t ldsBytes = (size_t)kParkGroups * 64 * sizeof(uint4) * (256 / 64);
+    const uint32_t blocks = std::min<uint32_t>((cnt + 511) / 512, 256 * 4);
+    hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, true>), dim3(blocks), dim3(256), ldsBytes, stream, S.ds, d_rays, cnt, S.d_workCounter, 0u, g_tune);
   } else {
     const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, 256 * 8);
-    hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, S.d_workCounter, 0u, g_tune);
+    hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, false>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, S.d_workCounter, 0u, g_tune);
   }
 }
 
@@ -309,8 +314,8 @@ int mi_scene_create(const mi_scene_desc* desc, mi_scene** out) {
     S->params.mesh_normals = nullptr; S->params.mat_ids = nullptr; S->params.materials = nullptr; S->params.bvh_nodes = nullptr;
     S->params.spheres = nullptr; S->params.discs = nullptr;
     if (const char* e = getenv("MI_RAYLIB_FULL_STATS")) g_fullStats = (e[0] == '1');
-    if (const char* e = getenv("MI_RAYLIB_TUNE")) { unsigned a, b, c, dd = 16, k8 = 2; if (sscanf(e, "%u,%u,%u,%u,%u", &a, &b, &c, &dd, &k8) >= 3) g_tune = {a, b, c, dd, k8}; }
-    if (const char* e = getenv("MI_RAYLIB_KERNEL")) g_kernelChoice = (e[0] == '0') ? 0 : (e[0] == '2') ? 2 : 1;
+    if (const char* e = getenv("MI_RAYLIB_TUNE")) { unsigned a, b, c, dd = 32, k8 = 2; if (sscanf(e, "%u,%u,%u,%u,%u", &a, &b, &c, &dd, &k8) >= 3) g_tune = {a, b, c, dd, k8}; }
+    if (const char* e = getenv("MI_RAYLIB_KERNEL")) g_kernelChoice = (e[0] == '0') ? 0 : (e[0] == '2') ? 2 : (e[0] == '3') ? 3 : 1;
   });
   if (rc != MI_OK) { delete S; return rc; }
   *out = S;
@@ -360,14 +365,14 @@ int mi_get_counters(mi_scene* scene, uint64_t counts[4]) {
   });
 }
 
-int mi_get_phase_stats(mi_scene* scene, uint64_t stats[8]) {
+int mi_get_phase_stats(mi_scene* scene, uint64_t stats[12]) {
   if (!scene || !stats) { g_err = "mi_get_phase_stats: null argument"; return MI_ERR_INVALID_ARG; }
   return guarded([&] {
     HIP_CHECK(hipSetDevice(scene->device));
     HIP_CHECK(hipDeviceSynchronize());
     unsigned long long h[16];
     HIP_CHECK(hipMemcpy(h, scene->d_counters, sizeof h, hipMemcpyDeviceToHost));
-    for (int i = 0; i < 8; ++i) stats[i] = h[4 + i];
+    for (int i = 0; i < 12; ++i) stats[i] = h[4 + i];
   });
 }
 

@@ -20,15 +20,25 @@
 
 namespace mi {
 
+// TWO_RAYS variant: every lane carries TWO pixels' state machines — one in registers
+// (active), one parked in LDS (36 dwords per lane, 9 KiB per wave). The vote counts both; before a phase
+// runs, lanes whose active ray is not in that phase but whose parked ray is swap the two (10 b128 LDS
+// writes + reads). A lane therefore takes part in a phase if EITHER of its rays is waiting for it, which
+// lifts the lanes-per-execution of every phase; the rays themselves are processed exactly as before.
+constexpr uint32_t kParkGroups = 9;      // uint4 groups per parked ray
+
 enum : uint32_t { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_GEN = 3, PH_FETCH = 4, PH_DONE = 5 };
 
-// Scheduling thresholds: a waiting phase runs as soon as this many lanes are parked in it; below the
-// thresholds NODE runs while it has any lane, and when nothing traverses the fullest phase runs.
-// Derivation of the defaults (a batch/occupancy trade-off under the 64-lane budget) is in DESIGN.md §6.
+// Scheduling weights (quarter units, NODE/TRAVERSE weigh 4) and traversal-burst limits; the defaults
+// {5, 8, 12, 32, 2} are the measured optimum on the box scene (+-2 % plateau):
+//   leafAt   inside a traversal burst, LEAF runs when cL*leafAt > cN*4
+//   shadeAt, genAt   top-level vote: SHADE/GEN run when their weighted population exceeds (cN+cL)*4
+//   burst    at most this many NODE/LEAF steps before the wave re-votes
+//   keep8    ... or earlier, once fewer than keep8/8 of the lanes that started the burst still traverse
 struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8; };
 
-template <bool STATS, bool LDS_NODES, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) path_trace_wavefront_kernel(DeviceScene sc, mi_trace_result* rays, uint32_t n,
+template <bool STATS, bool LDS_NODES, int BLOCK, bool TWO_RAYS>
+__global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : 1) path_trace_wavefront_kernel(DeviceScene sc, mi_trace_result* rays, uint32_t n,
                                                                    uint32_t* workCounter, uint32_t ldsNodeCount, WaveTune tune) {
   __shared__ float sinTbl[92];
   extern __shared__ __attribute__((aligned(16))) unsigned char dynLds[];
@@ -55,13 +65,53 @@ __global__ void __launch_bounds__(BLOCK) path_trace_wavefront_kernel(DeviceScene
   f3 o = mk(0, 0, 0), d = mk(0, 0, -1), nrm = mk(0, 0, 1), inv = mk(0, 0, 0);
   Shear sh; sh.kz = 2; sh.sx = sh.sy = 0.f; sh.sz = 1.f;
   Hit hit; hit.t = kInf; hit.leaf = 0xFFFFFFFFu; hit.geomID = 0xFFFFu; hit.b0 = hit.b1 = hit.b2 = 0.f;
-  uint32_t oFlags = 0, oPrim = MI_INVALID_PRIM, oGeom = MI_INVALID_GEOM;
+  uint32_t oFlags = 0, oLeaf = 0xFFFFFFFFu;   // oLeaf: leaf record of the last hit (-> primID, geomID at pixel end)
+  uint32_t phB = TWO_RAYS ? (uint32_t)PH_FETCH : (uint32_t)PH_DONE;   // phase of the ray parked in LDS
   bool exactSlab = false;
   float oTmax = kInf;
   CastStats cs = {0, 0};
   uint32_t casts = 0, paths = 0;
   // STATS only: per-wave phase executions and the lanes that were active in them (wave-uniform values)
   uint32_t itN = 0, itL = 0, itS = 0, itG = 0, lnN = 0, lnL = 0, lnS = 0, lnG = 0;
+  unsigned long long tTrav = 0, tShade = 0, tGen = 0, tLoop0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;   // STATS: shader cycles per phase
+
+  // Swap the register-resident ray with the parked one. Layout: group g of lane l of wave w at
+  // park[(w*kParkGroups + g)*64 + l] (uint4): consecutive lanes 16 B apart, conflict-free b128 accesses.
+  uint4* park = reinterpret_cast<uint4*>(dynLds) + (size_t)(threadIdx.x >> 6) * kParkGroups * 64 + lane;
+  auto swapRays = [&]() {
+    auto fu = [](float f) { return __float_as_uint(f); };
+    auto uf = [](uint32_t u) { return __uint_as_float(u); };
+    const uint32_t packed = ph | (bounce << 3) | (oFlags << 11) | (sh.kz << 13) | ((exactSlab ? 1u : 0u) << 15);
+    const uint4 w0 = make_uint4(fu(o.x), fu(o.y), fu(o.z), fu(d.x));
+    const uint4 w1 = make_uint4(fu(d.y), fu(d.z), fu(inv.x), fu(inv.y));
+    const uint4 w2 = make_uint4(fu(inv.z), fu(sh.sx), fu(sh.sy), fu(sh.sz));
+    const uint4 w3 = make_uint4(fu(hit.t), hit.leaf, node, pendLeaf);
+    const uint4 w4 = make_uint4(fu(tp.x), fu(tp.y), fu(tp.z), fu(color.x));
+    const uint4 w5 = make_uint4(fu(color.y), fu(color.z), fu(nrm.x), fu(nrm.y));
+    const uint4 w6 = make_uint4(fu(nrm.z), (uint32_t)rng.s0, (uint32_t)(rng.s0 >> 32), (uint32_t)rng.s1);
+    const uint4 w7 = make_uint4((uint32_t)(rng.s1 >> 32), pix, sample, fu(oTmax));
+    const uint4 w8 = make_uint4(oLeaf, packed, 0u, 0u);
+    const uint4 r0 = park[0 * 64], r1 = park[1 * 64], r2 = park[2 * 64], r3 = park[3 * 64], r4 = park[4 * 64];
+    const uint4 r5 = park[5 * 64], r6 = park[6 * 64], r7 = park[7 * 64], r8 = park[8 * 64];
+    park[0 * 64] = w0; park[1 * 64] = w1; park[2 * 64] = w2; park[3 * 64] = w3; park[4 * 64] = w4;
+    park[5 * 64] = w5; park[6 * 64] = w6; park[7 * 64] = w7; park[8 * 64] = w8;
+    o = mk(uf(r0.x), uf(r0.y), uf(r0.z)); d = mk(uf(r0.w), uf(r1.x), uf(r1.y));
+    inv = mk(uf(r1.z), uf(r1.w), uf(r2.x)); sh.sx = uf(r2.y); sh.sy = uf(r2.z); sh.sz = uf(r2.w);
+    hit.t = uf(r3.x); hit.leaf = r3.y; node = r3.z; pendLeaf = r3.w;
+    tp = mk(uf(r4.x), uf(r4.y), uf(r4.z)); color = mk(uf(r4.w), uf(r5.x), uf(r5.y));
+    nrm = mk(uf(r5.z), uf(r5.w), uf(r6.x));
+    rng.s0 = (uint64_t)r6.y | ((uint64_t)r6.z << 32); rng.s1 = (uint64_t)r6.w | ((uint64_t)r7.x << 32);
+    pix = r7.y; sample = r7.z; oTmax = uf(r7.w);
+    oLeaf = r8.x;
+    const uint32_t pk = r8.y;
+    ph = pk & 7u; bounce = (pk >> 3) & 0xFFu; oFlags = (pk >> 11) & 3u; sh.kz = (pk >> 13) & 3u; exactSlab = ((pk >> 15) & 1u) != 0;
+  };
+  if (TWO_RAYS) {
+    // park an initial FETCH-state ray so that the first swap brings in a ray that asks for a pixel
+    ph = PH_FETCH;
+    swapRays();           // registers <- uninitialised LDS (ignored: overwritten below), LDS <- FETCH-state ray
+    ph = PH_FETCH; bounce = 0; oFlags = 0; sh.kz = 2; exactSlab = false; hit.leaf = 0xFFFFFFFFu; oLeaf = 0xFFFFFFFFu;
+  }
 
   for (;;) {
     // ---------------- FETCH: cheap, always served first ----------------
@@ -76,7 +126,7 @@ __global__ void __launch_bounds__(BLOCK) path_trace_wavefront_kernel(DeviceScene
           pix = idx;
           const mi_trace_result* res = rays + idx;
           prow = res->u; pcol = res->v;
-          rgb = mk(res->rgb.x, res->rgb.y, res->rgb.z);
+          if (!TWO_RAYS) rgb = mk(res->rgb.x, res->rgb.y, res->rgb.z);   // TWO_RAYS accumulates rgb in memory
           rng_seed_pixel(rng, sc.rngSeed, prow, pcol);
           sample = 0;
           ph = PH_GEN;
@@ -87,100 +137,124 @@ __global__ void __launch_bounds__(BLOCK) path_trace_wavefront_kernel(DeviceScene
     }
 
     // ---------------- vote ----------------
-    const uint32_t cN = (uint32_t)__popcll(__ballot(ph == PH_NODE));
-    const uint32_t cL = (uint32_t)__popcll(__ballot(ph == PH_LEAF));
-    const uint32_t cS = (uint32_t)__popcll(__ballot(ph == PH_SHADE));
-    const uint32_t cG = (uint32_t)__popcll(__ballot(ph == PH_GEN));
-    if ((cN | cL | cS | cG) == 0) break;            // every lane DONE (FETCH lanes were just served)
-    // 0 = NODE, 1 = LEAF, 2 = SHADE, 3 = GEN
-    // weighted populations (quarter units): the phase with the largest weighted population runs
+    uint32_t cN = (uint32_t)__popcll(__ballot(ph == PH_NODE || (TWO_RAYS && phB == PH_NODE)));
+    uint32_t cL = (uint32_t)__popcll(__ballot(ph == PH_LEAF || (TWO_RAYS && phB == PH_LEAF)));
+    uint32_t cS = (uint32_t)__popcll(__ballot(ph == PH_SHADE || (TWO_RAYS && phB == PH_SHADE)));
+    uint32_t cG = (uint32_t)__popcll(__ballot(ph == PH_GEN || (TWO_RAYS && phB == PH_GEN)));
+    if (TWO_RAYS && __ballot(phB == PH_FETCH && ph != PH_FETCH)) {
+      // a parked ray still waits for its first pixel: bring it in, the FETCH service at the loop top serves it
+      if (phB == PH_FETCH && ph != PH_FETCH) { const uint32_t t = ph; swapRays(); phB = t; }
+      continue;
+    }
+    if ((cN | cL | cS | cG) == 0) break;            // every ray DONE (FETCH lanes were just served)
+    // Top-level vote: TRAVERSE (the NODE and LEAF populations together) against SHADE and GEN, by weighted
+    // population. Inside TRAVERSE a two-way mini-vote (two ballots) alternates box tests and primitive
+    // tests, so the expensive 4-way vote is only paid when the wave leaves traversal.
+    // run: 0 = TRAVERSE, 2 = SHADE, 3 = GEN; with TWO_RAYS the first phase of the traversal is also a swap point.
     uint32_t run;
     {
-      const uint32_t wN = cN * 4u, wL = cL * tune.leafAt, wS = cS * tune.shadeAt, wG = cG * tune.genAt;
-      const uint32_t other = max(wL, max(wS, wG));
-      if (cN > 0 && wN >= other) run = 0;
-      else run = (wL >= wS && wL >= wG) ? 1 : (wS >= wG ? 2 : 3);
+      const uint32_t wT = (cN + cL) * 4u, wS = cS * tune.shadeAt, wG = cG * tune.genAt;
+      if ((cN + cL) > 0 && wT >= max(wS, wG)) run = 0;
+      else run = (wS >= wG) ? 2 : 3;
+    }
+    if (TWO_RAYS) {
+      const bool wantT = run == 0;
+      const uint32_t want = run == 2 ? (uint32_t)PH_SHADE : (uint32_t)PH_GEN;
+      const bool needSwap = wantT ? ((ph != PH_NODE && ph != PH_LEAF) && (phB == PH_NODE || phB == PH_LEAF)) : (ph != want && phB == want);
+      if (__ballot(needSwap)) {
+        if (needSwap) { const uint32_t t = ph; swapRays(); phB = t; }
+      }
+      cN = (uint32_t)__popcll(__ballot(ph == PH_NODE)); cL = (uint32_t)__popcll(__ballot(ph == PH_LEAF));
+      cS = (uint32_t)__popcll(__ballot(ph == PH_SHADE)); cG = (uint32_t)__popcll(__ballot(ph == PH_GEN));
     }
 
     if (run == 0) {
-      // ---------------- NODE: one box test per lane ----------------
-      // NODE steps run in a short burst: re-voting costs about as much as a box test, so the wave keeps
-      // stepping while at least 3/4 of the lanes that started the burst are still traversing (<= 4 steps).
-      uint32_t stay = cN, burst = 0;
-      do {
-        if (STATS) { itN++; lnN += stay; }
-        if (ph == PH_NODE) {
-          GNode nd;
-          if (LDS_NODES && node < ldsNodeCount) nd = ldsNodes[node];
-          else nd = sc.nodes[node];
-          if (STATS) cs.nodes++;
-          // Box test (CompactBVH2Node.cpp:5-22, intersectRaySlab CompactBVH2Node.hpp:14-50).
-          // Fast form: with finite origin and finite inverse direction no slab product can be NaN, and for
-          // non-NaN values the reference's ordered compare/selects ARE min/max: swap(tmin,tmax) = (min,max),
-          // "t0 = tmin > t0 ? tmin : t0" = max, "t1 = tmax < t1 ? tmax : t1" = min, in any axis order; the
-          // sign of a zero never reaches the result (only t0 > t1 is used). Lanes whose ray has a zero /
-          // denormal direction component or a non-finite origin (exactSlab) redo the test with the
-          // reference's literal compare/select sequence below, so NaN cases stay bit-identical too.
-          const float maxx = nd.minx + half_bits_to_float(nd.hx);
-          const float maxy = nd.miny + half_bits_to_float(nd.hy);
-          const float maxz = nd.minz + half_bits_to_float(nd.hz);
-          const float ax = (nd.minx - o.x) * inv.x, bx = (maxx - o.x) * inv.x;
-          const float ay = (nd.miny - o.y) * inv.y, by = (maxy - o.y) * inv.y;
-          const float az = (nd.minz - o.z) * inv.z, bz = (maxz - o.z) * inv.z;
-          float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
-          float t1 = fminf(fminf(fmaxf(ax, bx) * kSlabScale, fmaxf(ay, by) * kSlabScale), fminf(fmaxf(az, bz) * kSlabScale, hit.t));
-          if (__ballot(exactSlab)) {
-            if (exactSlab) {
-              t0 = 0.f; t1 = hit.t;
-              { float tmin = ax, tmax = bx; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
-              { float tmin = ay, tmax = by; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
-              { float tmin = az, tmax = bz; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
+      // ---------------- TRAVERSE: NODE and LEAF steps under a two-way mini-vote ----------------
+      const unsigned long long tq0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+      const uint32_t startT = cN + cL;
+      uint32_t steps = 0;
+      for (;;) {
+        const uint32_t stay = cN;
+        if (cN * 4u >= cL * tune.leafAt && cN > 0) {
+          // NODE: one box test per lane
+          if (STATS) { itN++; lnN += stay; }
+          if (ph == PH_NODE) {
+            GNode nd;
+            if (LDS_NODES && node < ldsNodeCount) nd = ldsNodes[node];
+            else nd = sc.nodes[node];
+            if (STATS) cs.nodes++;
+            // Box test (CompactBVH2Node.cpp:5-22, intersectRaySlab CompactBVH2Node.hpp:14-50).
+            // Fast form: with finite origin and finite inverse direction no slab product can be NaN, and for
+            // non-NaN values the reference's ordered compare/selects ARE min/max: swap(tmin,tmax) = (min,max),
+            // "t0 = tmin > t0 ? tmin : t0" = max, "t1 = tmax < t1 ? tmax : t1" = min, in any axis order; the
+            // sign of a zero never reaches the result (only t0 > t1 is used). Lanes whose ray has a zero /
+            // denormal direction component or a non-finite origin (exactSlab) redo the test with the
+            // reference's literal compare/select sequence below, so NaN cases stay bit-identical too.
+            const float maxx = nd.minx + half_bits_to_float(nd.hx);
+            const float maxy = nd.miny + half_bits_to_float(nd.hy);
+            const float maxz = nd.minz + half_bits_to_float(nd.hz);
+            const float ax = (nd.minx - o.x) * inv.x, bx = (maxx - o.x) * inv.x;
+            const float ay = (nd.miny - o.y) * inv.y, by = (maxy - o.y) * inv.y;
+            const float az = (nd.minz - o.z) * inv.z, bz = (maxz - o.z) * inv.z;
+            float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
+            float t1 = fminf(fminf(fmaxf(ax, bx) * kSlabScale, fmaxf(ay, by) * kSlabScale), fminf(fmaxf(az, bz) * kSlabScale, hit.t));
+            if (__ballot(exactSlab)) {
+              if (exactSlab) {
+                t0 = 0.f; t1 = hit.t;
+                { float tmin = ax, tmax = bx; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
+                { float tmin = ay, tmax = by; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
+                { float tmin = az, tmax = bz; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
+              }
+            }
+            const bool boxHit = !(t0 > t1);
+            const bool isLeaf = nd.geomID != 0xFFFFu;
+            if (boxHit && isLeaf) {
+              pendLeaf = nd.link;
+              ph = PH_LEAF;
+            } else {
+              node = (boxHit || isLeaf) ? node + 1 : nd.link;
+              if (node >= numNodes) ph = PH_SHADE;
             }
           }
-          const bool boxHit = !(t0 > t1);
-          const bool isLeaf = nd.geomID != 0xFFFFu;
-          if (boxHit && isLeaf) {
-            pendLeaf = nd.link;
-            ph = PH_LEAF;
-          } else {
-            node = (boxHit || isLeaf) ? node + 1 : nd.link;
-            if (node >= numNodes) ph = PH_SHADE;
+        } else {
+          // LEAF: one primitive test per lane
+          if (STATS) { itL++; lnL += cL; }
+          if (ph == PH_LEAF) {
+            if (STATS) cs.leaves++;
+            const GLeaf L = sc.leaves[pendLeaf];
+            float t, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+            bool cand;
+            const uint32_t kind = leaf_kind(L);
+            if (kind == LEAF_TRI) {
+              t = intersect_triangle(mk(L.f[0], L.f[1], L.f[2]), mk(L.f[3], L.f[4], L.f[5]), mk(L.f[6], L.f[7], L.f[8]), o, sh, b0, b1, b2);
+              cand = t > 0.f && t < kInf;
+            } else if (kind == LEAF_SPHERE) {
+              t = intersect_sphere(L, o, d, 0.f);
+              cand = true;
+            } else {
+              t = intersect_disc(L, o, d);
+              cand = true;
+            }
+            if (cand && t > 0.f && t < hit.t) { hit.t = t; hit.leaf = pendLeaf; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2; }
+            node = node + 1;
+            ph = (node >= numNodes) ? PH_SHADE : PH_NODE;
           }
         }
-        stay = (uint32_t)__popcll(__ballot(ph == PH_NODE));
-      } while (++burst < tune.burst && stay * 8u >= cN * tune.keep8 && stay > 0);
-    } else if (run == 1) {
-      // ---------------- LEAF: one primitive test per lane ----------------
-      if (STATS) { itL++; lnL += cL; }
-      if (ph == PH_LEAF) {
-        if (STATS) cs.leaves++;
-        const GLeaf L = sc.leaves[pendLeaf];
-        float t, b0 = 0.f, b1 = 0.f, b2 = 0.f;
-        bool cand;
-        const uint32_t kind = leaf_kind(L);
-        if (kind == LEAF_TRI) {
-          t = intersect_triangle(mk(L.f[0], L.f[1], L.f[2]), mk(L.f[3], L.f[4], L.f[5]), mk(L.f[6], L.f[7], L.f[8]), o, sh, b0, b1, b2);
-          cand = t > 0.f && t < kInf;
-        } else if (kind == LEAF_SPHERE) {
-          t = intersect_sphere(L, o, d, 0.f);
-          cand = true;
-        } else {
-          t = intersect_disc(L, o, d);
-          cand = true;
-        }
-        if (cand && t > 0.f && t < hit.t) { hit.t = t; hit.leaf = pendLeaf; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2; }
-        node = node + 1;
-        ph = (node >= numNodes) ? PH_SHADE : PH_NODE;
+        cN = (uint32_t)__popcll(__ballot(ph == PH_NODE));
+        cL = (uint32_t)__popcll(__ballot(ph == PH_LEAF));
+        if (++steps >= tune.burst || (cN + cL) * 8u < startT * tune.keep8 || (cN + cL) == 0) break;
       }
+      if (STATS) tTrav += __builtin_amdgcn_s_memtime() - tq0;
     } else if (run == 2) {
       // ---------------- SHADE: traversal of bounce `bounce` is complete ----------------
       if (STATS) { itS++; lnS += cS; }
+      const unsigned long long tq1 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
       if (ph == PH_SHADE) {
         bool terminated = false;
         if (hit.leaf != 0xFFFFFFFFu) {
           const GLeaf L = sc.leaves[hit.leaf];
           hit.geomID = leaf_geom(L);
-          oGeom = hit.geomID; oPrim = L.primID; oTmax = hit.t;
+          oLeaf = hit.leaf; oTmax = hit.t;
           o = o + d * hit.t;                                          // updateHit, Render.hpp:15-23
           nrm = hit_normal(sc, hit, o);
           const mi_material mat = sc.materials[sc.matIDs[hit.geomID]];
@@ -201,7 +275,8 @@ __global__ void __launch_bounds__(BLOCK) path_trace_wavefront_kernel(DeviceScene
             d = nd2;
             if (refracted) tp = tp * albedo;
           } else {
-            rgb = rgb * __builtin_nanf("");
+            if (TWO_RAYS) { mi_trace_result* res = rays + pix; const float qn = __builtin_nanf(""); res->rgb = {res->rgb.x * qn, res->rgb.y * qn, res->rgb.z * qn}; }
+            else rgb = rgb * __builtin_nanf("");
             oFlags |= MI_FLAG_ERROR;
           }
         } else {
@@ -216,14 +291,17 @@ __global__ void __launch_bounds__(BLOCK) path_trace_wavefront_kernel(DeviceScene
         bounce++;
         if (bounce >= sc.maxPathLength) terminated = true;
         if (terminated) {
-          rgb = rgb + color;
+          mi_trace_result* res = rays + pix;
+          if (TWO_RAYS) { const mi_vec3 acc = res->rgb; res->rgb = {acc.x + color.x, acc.y + color.y, acc.z + color.z}; }
+          else rgb = rgb + color;
           ++paths;
           ++sample;
           if (sample < spp) ph = PH_GEN;
           else {
             // pixel complete: rgb sum + the LAST sample's hit record
-            mi_trace_result* res = rays + pix;
-            res->rgb = {rgb.x, rgb.y, rgb.z};
+            if (!TWO_RAYS) res->rgb = {rgb.x, rgb.y, rgb.z};
+            uint32_t oPrim = MI_INVALID_PRIM, oGeom = MI_INVALID_GEOM;
+            if (oLeaf != 0xFFFFFFFFu) { const GLeaf LL = sc.leaves[oLeaf]; oPrim = LL.primID; oGeom = leaf_geom(LL); }
             mi_hit_record hr;
             hr.r.origin = {o.x, o.y, o.z}; hr.r.t_min = 0.f;
             hr.r.direction = {d.x, d.y, d.z}; hr.r.t_max = oTmax;
@@ -246,17 +324,20 @@ __global__ void __launch_bounds__(BLOCK) path_trace_wavefront_kernel(DeviceScene
           ph = (numNodes > 0) ? PH_NODE : PH_SHADE;
         }
       }
+      if (STATS) tShade += __builtin_amdgcn_s_memtime() - tq1;
     } else {
       // ---------------- GEN: camera ray of the next sample ----------------
       if (STATS) { itG++; lnG += cG; }
+      const unsigned long long tq2 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
       if (ph == PH_GEN) {
+        if (TWO_RAYS) { prow = rays[pix].u; pcol = rays[pix].v; }     // not part of the parked state
         float g0, g1;
         rng_gauss2(rng, sinTbl, g0, g1);
         const float jr = prow + sc.antiAliasScale * g0, jc = pcol + sc.antiAliasScale * g1;
         d = pixel_to_ray_dir(jc, jr, sc.imageWidth, sc.imageHeight, sc.tanTheta);
         o = mk(0.f, 0.f, 0.f);
         nrm = mk(0.f, 0.f, 1.f);                         // HitRecord ctor, geometry.hpp:236-242
-        oPrim = MI_INVALID_PRIM; oGeom = MI_INVALID_GEOM; oFlags = 0; oTmax = kInf;
+        oLeaf = 0xFFFFFFFFu; oFlags = 0; oTmax = kInf;
         tp = mk(1.f, 1.f, 1.f);
         color = mk(0.f, 0.f, 0.f);
         bounce = 0;
@@ -269,6 +350,7 @@ __global__ void __launch_bounds__(BLOCK) path_trace_wavefront_kernel(DeviceScene
         ++casts;
         ph = (numNodes > 0) ? PH_NODE : PH_SHADE;
       }
+      if (STATS) tGen += __builtin_amdgcn_s_memtime() - tq2;
     }
   }
   flush_stats(sc, casts, cs, paths);
@@ -277,6 +359,8 @@ __global__ void __launch_bounds__(BLOCK) path_trace_wavefront_kernel(DeviceScene
     atomicAdd(&sc.counters[6], (unsigned long long)itL); atomicAdd(&sc.counters[7], (unsigned long long)lnL);
     atomicAdd(&sc.counters[8], (unsigned long long)itS); atomicAdd(&sc.counters[9], (unsigned long long)lnS);
     atomicAdd(&sc.counters[10], (unsigned long long)itG); atomicAdd(&sc.counters[11], (unsigned long long)lnG);
+    atomicAdd(&sc.counters[12], tTrav); atomicAdd(&sc.counters[13], tShade); atomicAdd(&sc.counters[14], tGen);
+    atomicAdd(&sc.counters[15], __builtin_amdgcn_s_memtime() - tLoop0);
   }
 }
 

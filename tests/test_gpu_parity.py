@@ -83,11 +83,11 @@ def test_traversal_visits_exactly_the_reference_nodes(scenes, monkeypatch):
 # ------------------------------------------------------------------------------------------------------
 # path trace: rgb sums + last-sample hit records, per-pixel RNG streams
 # ------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("kernel", ["0", "1", "2"])
+@pytest.mark.parametrize("kernel", ["0", "1", "2", "3"])
 @pytest.mark.parametrize("name,size,spp", [("box-simple", 128, 32), ("box", 160, 24), ("spheres", 128, 32)])
 def test_path_trace_bit_exact(scenes, name, size, spp, kernel, monkeypatch):
     """kernel 0 = nested-loop kernel, 1 = phase-scheduled persistent kernel, 2 = the same with the BVH
-    prefix staged in LDS; 1 is the default. All three must reproduce the oracle bit for bit."""
+    prefix staged in LDS, 3 = two rays per lane (second one parked in LDS). All three must reproduce the oracle bit for bit."""
     monkeypatch.setenv("MI_RAYLIB_KERNEL", kernel)
     s = scenes[name]
     s.desc.set_image(size, size)
