@@ -11,7 +11,10 @@
 // to binary16; weights and inter-layer activations are binary16; products accumulate in binary32
 // on v_mfma_f32_16x16x32_f16 (the IPU accumulates in half: ours is the more accurate of the two).
 //
-// Kernel shape: one 256-thread workgroup owns 64 rays. Activations live in LDS as
+// Kernel shape: one 512-thread workgroup owns 128 rays; wave w evaluates output-feature
+// tiles {w&3, (w&3)+4, ...} for the 64 rays of row half w>>2, so each packed weight fragment is fetched
+// by two waves (second one hits L1) and amortised over 4 MFMAs; the next k-step's fragments are
+// prefetched into a second register set while the current ones feed the matrix cores. Activations live in LDS as
 // [64][stride] binary16; the dense layers are evaluated transposed, Y^T = W^T · X^T, so that the
 // MFMA result fragment of a lane is 4 consecutive output features of ONE ray and goes back to LDS
 // as one 8-byte store. W^T is pre-packed on the host in exact A-fragment order, so every weight
@@ -20,6 +23,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -33,7 +37,8 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 
-constexpr uint32_t kNifRows = 64;        // rays per workgroup pass
+constexpr uint32_t kNifRows = 128;       // rays per workgroup pass (8 waves: 4 output-feature groups x 2 row halves)
+constexpr uint32_t kNifThreads = 512;
 constexpr uint32_t kNifMaxLayers = 16;
 constexpr uint32_t kNifMaxTilesPerWave = 6;   // output-feature tiles (of 16) per wave: supports widths up to 384
 
@@ -110,7 +115,7 @@ struct NifDevice {
       }
       if (N > 16 * kNifMaxTilesPerWave * 4) throw std::invalid_argument("NIF: layer too wide");
       if (l + 1 < numLayers && N > featBase) throw std::invalid_argument("NIF: internal width error");
-      L.kSteps = (K + 31) / 32; L.nTiles = (N + 15) / 16; L.n = N; L.relu = relu[l] ? 1u : 0u;
+      L.kSteps = (K + 31) / 32; L.nTiles = (((N + 15) / 16) + 3u) & ~3u; L.n = N; L.relu = relu[l] ? 1u : 0u;   // tiles padded to a multiple of 4: every wave owns nTiles/4 of them
       L.wOffset = (uint32_t)(packed.size() / 8);
       for (uint32_t nt = 0; nt < L.nTiles; ++nt)
         for (uint32_t ks = 0; ks < L.kSteps; ++ks)
@@ -144,6 +149,20 @@ struct NifDevice {
     indexCap = n;
   }
 };
+
+// sin and cos of a phase that is a binary16 value (|p| <= 65504). Cody-Waite reduction to
+// r = p - k*2pi (k = nearest integer of p/2pi, 2pi split in three parts so the products are exact for the
+// <= 11-bit significand of p and |k| < 2^14), then the hardware v_sin/v_cos on r/2pi. Absolute error
+// ~1e-6, far below the binary16 rounding (4.9e-4) applied to the result (NifModel.cpp:212-216).
+__device__ __forceinline__ void sincos_half_phase(float p, float& sn, float& cs) {
+  const float k = rintf(p * 0.15915494309189535f);
+  float r = fmaf(-k, 6.28125f, p);                       // 2pi = 6.28125 + 1.9350051879882812e-3 + 3.0199159819e-7
+  r = fmaf(-k, 1.9350051879882812e-3f, r);
+  r = fmaf(-k, 3.0199159819e-7f, r);
+  const float rev = r * 0.15915494309189535f;            // |rev| <= 0.5
+  sn = __builtin_amdgcn_sinf(rev);
+  cs = __builtin_amdgcn_cosf(rev);
+}
 
 // PreProcessEscapedRays + compaction. u/v are written for EVERY ray (0 for rays that did not escape,
 // as the reference does); `index[0..*count)` receives the escaped rays' indices, one atomic per wave.
@@ -179,12 +198,14 @@ __global__ void __launch_bounds__(256) escaped_uv_kernel(const mi_trace_result* 
 // The MLP. rows: `numRows` (or *countPtr when countPtr != nullptr) entries; entry r reads
 // u[idx ? idx[r] : r], v[...]; result goes to bgrOut[3*r..] (stand-alone) and/or is added to
 // rays[idx[r]].rgb as throughput * (b,g,r)->(r,g,b) (PostProcessEscapedRays).
-__global__ void __launch_bounds__(256) nif_mlp_kernel(NifParams P, const h8* __restrict__ weights, const float* __restrict__ bias,
+template <uint32_t TILES>
+__global__ void __launch_bounds__(kNifThreads) nif_mlp_kernel(NifParams P, const h8* __restrict__ weights, const float* __restrict__ bias,
                                                       const float* __restrict__ u, const float* __restrict__ v,
                                                       const uint32_t* __restrict__ idx, const uint32_t* __restrict__ countPtr,
                                                       uint32_t numRows, float* __restrict__ bgrOut, mi_trace_result* rays) {
   extern __shared__ __attribute__((aligned(16))) _Float16 X[];   // [kNifRows][P.stride]
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t ng = wave & 3u, rowBase = 64u * (wave >> 2);    // output-feature group, row half
   const uint32_t total = countPtr ? *countPtr : numRows;
   const uint32_t stride = P.stride;
   const uint32_t E = P.embedDim, F = 4 * E;
@@ -203,7 +224,9 @@ __global__ void __launch_bounds__(256) nif_mlp_kernel(NifParams P, const h8* __r
       if (row < total) { const uint32_t src = idx ? idx[row] : row; coord = isV ? v[src] : u[src]; }
       const float nrm = (coord - 1.f) * 2.f;                                  // NifModel.cpp:203-205
       const float phase = (float)(_Float16)(nrm * (float)(1u << j));           // cast to HALF before sin/cos (:212)
-      const _Float16 sn = (_Float16)sinf(phase), cs = (_Float16)cosf(phase);
+      float fs, fc;
+      sincos_half_phase(phase, fs, fc);
+      const _Float16 sn = (_Float16)fs, cs = (_Float16)fc;
       // feature order [sin u | sin v | cos u | cos v] (NifModel.cpp:216)
       X[r * stride + P.featBase + isV * E + j] = sn;
       X[r * stride + P.featBase + 2 * E + isV * E + j] = cs;
@@ -212,33 +235,57 @@ __global__ void __launch_bounds__(256) nif_mlp_kernel(NifParams P, const h8* __r
 
     for (uint32_t l = 0; l < P.numLayers; ++l) {
       const NifLayerDesc L = P.layers[l];
-      f4v acc[kNifMaxTilesPerWave][4];
+      f4v acc[TILES][4];
 #pragma unroll
-      for (uint32_t a = 0; a < kNifMaxTilesPerWave; ++a)
+      for (uint32_t a = 0; a < TILES; ++a)
 #pragma unroll
         for (uint32_t m = 0; m < 4; ++m) acc[a][m] = (f4v){0.f, 0.f, 0.f, 0.f};
-      // this wave's output-feature tiles: wave, wave+4, wave+8, ...
-      for (uint32_t ks = 0; ks < L.kSteps; ++ks) {
-        h8 xb[4];
+      const uint32_t tilesLayer = L.nTiles >> 2;            // tiles per wave in this layer (wave-uniform)
+      const h8* wbase = weights + L.wOffset + lane;
+      if (tilesLayer == TILES) {
+        // Fast path (the hidden layers): fully unrolled over this wave's TILES tiles; the next k-step's
+        // weight fragments are in flight while the current ones feed the matrix cores.
+        h8 wc[TILES], wn[TILES];
 #pragma unroll
-        for (uint32_t m = 0; m < 4; ++m)   // B fragment: X^T[k][ray] = X[ray = 16m + (lane&15)][k = 32ks + 8(lane>>4) + j]
-          xb[m] = *reinterpret_cast<const h8*>(&X[(16 * m + (lane & 15)) * stride + L.inBase + 32 * ks + 8 * (lane >> 4)]);
+        for (uint32_t a = 0; a < TILES; ++a) wc[a] = wbase[((size_t)(ng + 4 * a) * L.kSteps) * 64];
+        for (uint32_t ks = 0; ks < L.kSteps; ++ks) {
+          const uint32_t kn = (ks + 1 < L.kSteps) ? ks + 1 : ks;
 #pragma unroll
-        for (uint32_t a = 0; a < kNifMaxTilesPerWave; ++a) {
-          const uint32_t nt = wave + 4 * a;
-          if (nt < L.nTiles) {
-            const h8 wa = weights[L.wOffset + ((size_t)nt * L.kSteps + ks) * 64 + lane];
+          for (uint32_t a = 0; a < TILES; ++a) wn[a] = wbase[((size_t)(ng + 4 * a) * L.kSteps + kn) * 64];
+          h8 xb[4];
 #pragma unroll
-            for (uint32_t m = 0; m < 4; ++m) acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xb[m], acc[a][m], 0, 0, 0);
+          for (uint32_t m = 0; m < 4; ++m)   // B fragment: X^T[k][ray] = X[ray = rowBase + 16m + (lane&15)][k = 32ks + 8(lane>>4) + j]
+            xb[m] = *reinterpret_cast<const h8*>(&X[(rowBase + 16 * m + (lane & 15)) * stride + L.inBase + 32 * ks + 8 * (lane >> 4)]);
+#pragma unroll
+          for (uint32_t a = 0; a < TILES; ++a)
+#pragma unroll
+            for (uint32_t m = 0; m < 4; ++m) acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[a], xb[m], acc[a][m], 0, 0, 0);
+#pragma unroll
+          for (uint32_t a = 0; a < TILES; ++a) wc[a] = wn[a];
+        }
+      } else {
+        // Generic path (e.g. the 3-wide output layer): one tile at a time, rolled.
+        for (uint32_t ks = 0; ks < L.kSteps; ++ks) {
+          h8 xb[4];
+#pragma unroll
+          for (uint32_t m = 0; m < 4; ++m)
+            xb[m] = *reinterpret_cast<const h8*>(&X[(rowBase + 16 * m + (lane & 15)) * stride + L.inBase + 32 * ks + 8 * (lane >> 4)]);
+#pragma unroll
+          for (uint32_t a = 0; a < TILES; ++a) {
+            if (a < tilesLayer) {
+              const h8 w = wbase[((size_t)(ng + 4 * a) * L.kSteps + ks) * 64];
+#pragma unroll
+              for (uint32_t m = 0; m < 4; ++m) acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, xb[m], acc[a][m], 0, 0, 0);
+            }
           }
         }
       }
       __syncthreads();   // every wave has read its inputs: X[.., 0..N) may be overwritten
       const bool last = (l + 1 == P.numLayers);
 #pragma unroll
-      for (uint32_t a = 0; a < kNifMaxTilesPerWave; ++a) {
-        const uint32_t nt = wave + 4 * a;
-        if (nt < L.nTiles) {
+      for (uint32_t a = 0; a < TILES; ++a) {
+        const uint32_t nt = ng + 4 * a;
+        if (a < tilesLayer && 16 * nt < L.n) {
           // D fragment: rows (= output features) 16nt + 4(lane>>4) + reg, column (= ray) 16m + (lane&15)
           const uint32_t f0 = 16 * nt + 4 * (lane >> 4);
 #pragma unroll
@@ -252,7 +299,7 @@ __global__ void __launch_bounds__(256) nif_mlp_kernel(NifParams P, const h8* __r
 #pragma unroll
               for (int q = 0; q < 4; ++q) y[q] = y[q] > 0.f ? y[q] : 0.f;
             }
-            const uint32_t r = 16 * m + (lane & 15);
+            const uint32_t r = rowBase + 16 * m + (lane & 15);
             if (!last) {
               h4 yh = {(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
               *reinterpret_cast<h4*>(&X[r * stride + f0]) = yh;
@@ -288,8 +335,15 @@ inline void nif_launch_mlp(const NifDevice& nif, const float* u, const float* v,
   const size_t lds = (size_t)kNifRows * nif.p.stride * sizeof(_Float16);
   uint32_t blocks = (numRows + kNifRows - 1) / kNifRows;
   if (blocks > 256 * 8) blocks = 256 * 8;          // grid-stride beyond 8 row-blocks per CU
-  hipLaunchKernelGGL(nif_mlp_kernel, dim3(blocks), dim3(256), lds, stream, nif.p, nif.d_weights, nif.d_bias, u, v, idx, countPtr,
-                     numRows, bgrOut, rays);
+  uint32_t maxTiles = 1;
+  for (uint32_t l = 0; l < nif.p.numLayers; ++l) maxTiles = std::max(maxTiles, nif.p.layers[l].nTiles / 4);
+  auto launch = [&](auto kern) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kNifThreads), lds, stream, nif.p, nif.d_weights, nif.d_bias, u, v, idx, countPtr, numRows, bgrOut, rays);
+  };
+  if (maxTiles <= 2) launch(nif_mlp_kernel<2>);
+  else if (maxTiles <= 5) launch(nif_mlp_kernel<5>);
+  else launch(nif_mlp_kernel<6>);
 }
 
 // mi_nif_infer_device: every row is evaluated (no compaction)

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Throughput of K3 (the NIF MLP on MFMA): rays/s and TFLOP/s against the dense f16 MFMA peak.
+Weights: synthetic, the reference's shapes (48->320->320->320->(320+48)->320->320->3, nif_metadata.txt)."""
+import json, sys, time
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import torch
+import ipu_ray_lib_amd as irl
+
+MFMA_F16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense
+
+
+def weights(rng, hidden=320, embed=12, layers=6):
+    F = 4 * embed
+    dims = [(F, hidden)] + [((hidden + F) if l == layers // 2 else hidden, hidden) for l in range(1, layers)] + [(hidden, 3)]
+    ks = [(rng.normal(size=d) * np.sqrt(2.0 / d[0])).astype(np.float32) for d in dims]
+    bs = [(rng.normal(size=d[1]) * 0.05).astype(np.float32) for d in dims]
+    return ks, bs, [1] * (len(dims) - 1) + [0], dims
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1440 * 1440
+    rng = np.random.default_rng(0)
+    ks, bs, relu, dims = weights(rng)
+    s = irl.HostScene.builtin("spheres")
+    dev = irl.IpuScene(s.desc)
+    dev.setNif(ks, bs, relu, 12, 3.43, np.array([-2.35, -2.27, -1.96], np.float32), True)
+    u = torch.rand(n, device="cuda"); v = torch.rand(n, device="cuda"); out = torch.empty(n, 3, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):
+        dev.nif_infer_device(u.data_ptr(), v.data_ptr(), out.data_ptr(), n, st)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        dev.nif_infer_device(u.data_ptr(), v.data_ptr(), out.data_ptr(), n, st)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops_per_ray = 2 * sum(k * c for k, c in dims)
+    tf = n * flops_per_ray / (ms * 1e-3) / 1e12
+    print(json.dumps({"kernel": "nif_mlp_kernel", "rays": n, "ms": ms, "rays_per_s": n / (ms * 1e-3), "flops_per_ray": flops_per_ray,
+                      "tflops": tf, "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F16_PEAK_TFLOPS}}))
+
+
+if __name__ == "__main__":
+    main()
