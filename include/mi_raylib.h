@@ -134,8 +134,10 @@ void mi_scene_destroy(mi_scene* scene);
  * mode only rays[i].u/.v matter on input (camera rays are regenerated per sample on the device,
  * codelets/TraceCodelets.cpp:142-164); rgb comes back as the sum over samples_per_pixel samples.
  * In shadow-trace mode the given rays are traced as they are (Render.hpp:37-72).
- * `cb` (may be NULL) mirrors IpuScene::RayCallbackFn: it is called once per completed batch with
- * (user, batch_index, first_ray, ray_count) on the calling thread. */
+ * `cb` (may be NULL) mirrors IpuScene::RayCallbackFn: it is called once per completed batch (see
+ * mi_scene_set_ray_batch) with (user, batch_index, first_ray, ray_count), in batch order, on the calling
+ * thread, while later batches are still being traced. The timed region (mi_trace_time_secs) here includes the
+ * batch copies, which the pipeline overlaps with tracing. */
 typedef void (*mi_ray_callback)(void* user, size_t batch_index, const mi_trace_result* rays, size_t count);
 int mi_render(mi_scene* scene, int mode, mi_trace_result* rays, size_t n, mi_ray_callback cb, void* user);
 
@@ -178,6 +180,12 @@ int mi_scene_set_nif(mi_scene* scene, uint32_t num_layers,
 /* Replaces: IpuScene::setHdriRotation (degrees) / setMaxNifBatchSize (src/IpuScene.cpp:334-344). */
 int mi_scene_set_hdri_rotation(mi_scene* scene, float degrees);
 int mi_scene_set_max_nif_batch(mi_scene* scene, size_t rays_per_batch);
+
+/* Replaces: the `raysPerWorker` constructor argument / --rays-per-worker (src/IpuScene.cpp:360-361, 110-172):
+ * mi_render cuts the host ray stream into batches of this many rays (the reference: 1440 tiles x 6 workers x
+ * raysPerWorker), pipelines their upload / trace / download on two HIP streams and calls the ray callback once
+ * per finished batch, in batch order. 0 (default) = one batch. Results do not depend on the batch size. */
+int mi_scene_set_ray_batch(mi_scene* scene, size_t rays_per_batch);
 
 /* The NIF environment evaluated stand-alone on device arrays: for i<n, bgr[i*3..] =
  * decode(MLP(fourier(u[i], v[i]))). Replaces NifModel::buildInference's execModel

@@ -148,6 +148,7 @@ def device_lib() -> C.CDLL:
                                          C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_int32]
         lib.mi_scene_set_hdri_rotation.argtypes = [C.c_void_p, C.c_float]
         lib.mi_scene_set_max_nif_batch.argtypes = [C.c_void_p, C.c_size_t]
+        lib.mi_scene_set_ray_batch.argtypes = [C.c_void_p, C.c_size_t]
         lib.mi_nif_infer_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         _device = lib
     return _device
@@ -269,6 +270,9 @@ class IpuScene:
     def setMaxNifBatchSize(self, rays_per_batch: int):
         _check_dev(self._lib.mi_scene_set_max_nif_batch(self._h, int(rays_per_batch)))
 
+    def setRayBatch(self, rays_per_batch: int):
+        _check_dev(self._lib.mi_scene_set_ray_batch(self._h, int(rays_per_batch)))
+
     def getTraceTimeSecs(self) -> float:
         return float(self._lib.mi_trace_time_secs(self._h))
 
@@ -287,12 +291,18 @@ class IpuScene:
                                               int(embedding_dimension), float(max_value), mean_a.ctypes.data,
                                               1 if log_tonemap else 0))
 
-    def run(self, rays: np.ndarray, mode: int | None = None) -> np.ndarray:
-        """GraphManager().run(ipuScene): trace the HOST ray stream in place."""
+    def run(self, rays: np.ndarray, mode: int | None = None, callback=None) -> np.ndarray:
+        """GraphManager().run(ipuScene): trace the HOST ray stream in place. `callback(batch_index, first, count)`
+        mirrors IpuScene::RayCallbackFn (one call per finished ray batch, see setRayBatch)."""
         assert rays.dtype == TRACE_RESULT and rays.flags["C_CONTIGUOUS"]
         if mode is None:
             mode = MODE_PATH_TRACE if self.desc.path_trace else MODE_SHADOW_TRACE
-        _check_dev(self._lib.mi_render(self._h, mode, rays.ctypes.data, rays.size, None, None))
+        cb = None
+        if callback is not None:
+            base = rays.ctypes.data
+            proto = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t)
+            cb = proto(lambda user, idx, ptr, cnt: callback(idx, (ptr - base) // TRACE_RESULT.itemsize, cnt))
+        _check_dev(self._lib.mi_render(self._h, mode, rays.ctypes.data, rays.size, cb, None))
         return rays
 
     def run_device(self, d_rays_ptr: int, n: int, mode: int, stream: int = 0):

@@ -105,6 +105,8 @@ class IpuScene {
     }
     mi_scene_set_hdri_rotation(scene, hdriRotationDegrees);
     mi_scene_set_max_nif_batch(scene, nifMaxRaysPerBatch);
+    // batch = 1440 compute tiles x 6 workers x raysPerWorker rays, as on one IPU (src/IpuScene.cpp:360-361)
+    if (rayFunc) mi_scene_set_ray_batch(scene, (size_t)1440 * 6 * (maxRaysPerWorker ? maxRaysPerWorker : 1));
     const int mode = data.path_trace ? MI_MODE_PATH_TRACE : MI_MODE_SHADOW_TRACE;
     if (mi_render(scene, mode, rayStream.data(), rayStream.size(), rayFunc ? &IpuScene::trampoline : nullptr, this) != MI_OK)
       return fail("render");

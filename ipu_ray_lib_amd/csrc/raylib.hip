@@ -81,6 +81,7 @@ struct mi_scene {
   double traceTimeSecs = 0.0;
   float hdriRotationDegrees = 0.f;
   size_t maxNifBatch = 0;
+  size_t rayBatch = 0;               // rays per mi_render batch (0 = the whole stream in one batch)
   NifDevice nif;
   // scratch for the per-sample NIF loop
   Rng* d_rng = nullptr; float* d_u = nullptr; float* d_v = nullptr; float* d_bgr = nullptr; size_t scratchRays = 0;
@@ -206,7 +207,7 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
   S.keep(S.d_counters);
   HIP_CHECK(hipMemset(S.d_counters, 0, 16 * sizeof(unsigned long long)));
   ds.counters = S.d_counters;
-  HIP_CHECK(hipMalloc(&S.d_workCounter, sizeof(uint32_t)));
+  HIP_CHECK(hipMalloc(&S.d_workCounter, 2 * sizeof(uint32_t)));      // one per pipeline slot (mi_render batches)
   S.keep(S.d_workCounter);
 }
 
@@ -231,8 +232,9 @@ int g_kernelChoice = 1;           // 0 = nested-loop kernel, 1 = wavefront (glob
 constexpr uint32_t kLdsBudgetBytes = 160 * 1024 - 1024;     // 160 KiB per CU minus the static allocations
 
 template <bool STATS>
-void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStream_t stream) {
-  HIP_CHECK(hipMemsetAsync(S.d_workCounter, 0, sizeof(uint32_t), stream));
+void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStream_t stream, int slot) {
+  uint32_t* workCounter = S.d_workCounter + slot;
+  HIP_CHECK(hipMemsetAsync(workCounter, 0, sizeof(uint32_t), stream));
   if (g_kernelChoice == 2 && S.ds.numNodes > 0) {
     // one 1024-thread workgroup per CU shares one LDS copy of the first nodes of the (preorder) array
     const uint32_t ldsNodes = std::min<uint32_t>(S.ds.numNodes, kLdsBudgetBytes / (uint32_t)sizeof(GNode));
@@ -241,19 +243,19 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
     static bool attrSet = false;
     if (!attrSet) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes)); attrSet = true; }
     const uint32_t blocks = std::min<uint32_t>((cnt + 1023) / 1024, 256);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), ldsBytes, stream, S.ds, d_rays, cnt, S.d_workCounter, ldsNodes, g_tune);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, ldsNodes, g_tune);
   } else if (g_kernelChoice == 3 && !S.ds.hasNormals) {
     // two rays per lane, the second parked in LDS: 9 uint4 groups x 64 lanes x 4 waves = 36 KiB per workgroup
     const size_t ldsBytes = (size_t)kParkGroups * 64 * sizeof(uint4) * (256 / 64);
     const uint32_t blocks = std::min<uint32_t>((cnt + 511) / 512, 256 * 4);
-    hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, true>), dim3(blocks), dim3(256), ldsBytes, stream, S.ds, d_rays, cnt, S.d_workCounter, 0u, g_tune);
+    hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, true>), dim3(blocks), dim3(256), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune);
   } else {
     const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, 256 * 8);
-    hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, false>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, S.d_workCounter, 0u, g_tune);
+    hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, false>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune);
   }
 }
 
-void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipStream_t stream) {
+void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipStream_t stream, int slot = 0) {
   if (n == 0) return;
   if (n > 0xFFFFFFFFull) throw ArgError("mi_render: more than 2^32-1 rays in one call");
   const uint32_t cnt = (uint32_t)n;
@@ -265,8 +267,8 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
   } else if (mode == MI_MODE_PATH_TRACE) {
     if (!S.nif.loaded() && g_kernelChoice != 0 && S.ds.samplesPerPixel >= 1 && S.ds.maxPathLength >= 1) {
       // sample loop inside the kernel (src/IpuScene.cpp:441), phase-scheduled persistent form
-      if (g_fullStats) launchWavefront<true>(S, d_rays, cnt, stream);
-      else launchWavefront<false>(S, d_rays, cnt, stream);
+      if (g_fullStats) launchWavefront<true>(S, d_rays, cnt, stream, slot);
+      else launchWavefront<false>(S, d_rays, cnt, stream, slot);
     } else if (!S.nif.loaded()) {
       // sample loop inside the kernel (src/IpuScene.cpp:441: vertexSampleCount = samplesPerPixel)
       if (g_fullStats) hipLaunchKernelGGL(path_trace_kernel<true>, grid, block, 0, stream, S.ds, d_rays, cnt, 0u, S.ds.samplesPerPixel, (Rng*)nullptr);
@@ -337,18 +339,36 @@ int mi_render(mi_scene* scene, int mode, mi_trace_result* rays, size_t n, mi_ray
   return guarded([&] {
     HIP_CHECK(hipSetDevice(scene->device));
     if (n == 0) { scene->traceTimeSecs = 0.0; return; }
-    mi_trace_result* d = nullptr;
-    HIP_CHECK(hipMalloc(&d, n * sizeof(mi_trace_result)));
+    // Ray batches (src/IpuScene.cpp:110-172, 585-618): the stream is cut into batches of rayBatch rays that
+    // flow through a two-slot pipeline — upload, trace and download of batch b+1 overlap the download and
+    // the callback of batch b — each slot on its own HIP stream. Every pixel owns its RNG stream, so the
+    // result does not depend on the batch size. The NIF path shares scratch buffers and runs one slot.
+    const size_t batch = (scene->rayBatch && scene->rayBatch < n) ? scene->rayBatch : n;
+    const size_t numBatches = (n + batch - 1) / batch;
+    const int slots = (numBatches > 1 && !scene->nif.loaded()) ? 2 : 1;
+    mi_trace_result* d[2] = {nullptr, nullptr};
+    hipStream_t st[2] = {nullptr, nullptr};
+    auto cleanup = [&] { for (int i = 0; i < 2; ++i) { if (d[i]) (void)hipFree(d[i]); if (st[i]) (void)hipStreamDestroy(st[i]); } };
     try {
-      HIP_CHECK(hipMemcpy(d, rays, n * sizeof(mi_trace_result), hipMemcpyHostToDevice));
-      const auto t0 = std::chrono::steady_clock::now();     // like src/IpuScene.cpp:692-696: upload excluded
-      launchRender(*scene, mode, d, n, nullptr);
-      HIP_CHECK(hipDeviceSynchronize());
+      for (int i = 0; i < slots; ++i) { HIP_CHECK(hipMalloc(&d[i], batch * sizeof(mi_trace_result))); HIP_CHECK(hipStreamCreate(&st[i])); }
+      const auto t0 = std::chrono::steady_clock::now();
+      auto finish = [&](size_t b) {
+        HIP_CHECK(hipStreamSynchronize(st[b % slots]));
+        const size_t first = b * batch, cnt = std::min(batch, n - first);
+        if (cb) cb(user, b, rays + first, cnt);              // RayCallback::fetch, src/RayCallback.cpp:8-24
+      };
+      for (size_t b = 0; b < numBatches; ++b) {
+        const int i = (int)(b % slots);
+        if (b >= (size_t)slots) finish(b - slots);
+        const size_t first = b * batch, cnt = std::min(batch, n - first);
+        HIP_CHECK(hipMemcpyAsync(d[i], rays + first, cnt * sizeof(mi_trace_result), hipMemcpyHostToDevice, st[i]));
+        launchRender(*scene, mode, d[i], cnt, st[i], i);
+        HIP_CHECK(hipMemcpyAsync(rays + first, d[i], cnt * sizeof(mi_trace_result), hipMemcpyDeviceToHost, st[i]));
+      }
+      for (size_t b = (numBatches > (size_t)slots ? numBatches - slots : 0); b < numBatches; ++b) finish(b);
       scene->traceTimeSecs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      HIP_CHECK(hipMemcpy(rays, d, n * sizeof(mi_trace_result), hipMemcpyDeviceToHost));
-    } catch (...) { (void)hipFree(d); throw; }
-    HIP_CHECK(hipFree(d));
-    if (cb) cb(user, 0, rays, n);
+    } catch (...) { (void)hipDeviceSynchronize(); cleanup(); throw; }
+    cleanup();
   });
 }
 
@@ -405,6 +425,12 @@ int mi_scene_set_hdri_rotation(mi_scene* scene, float degrees) {
 int mi_scene_set_max_nif_batch(mi_scene* scene, size_t rays_per_batch) {
   if (!scene) { g_err = "null scene"; return MI_ERR_INVALID_ARG; }
   scene->maxNifBatch = rays_per_batch;
+  return MI_OK;
+}
+
+int mi_scene_set_ray_batch(mi_scene* scene, size_t rays_per_batch) {
+  if (!scene) { g_err = "null scene"; return MI_ERR_INVALID_ARG; }
+  scene->rayBatch = rays_per_batch;
   return MI_OK;
 }
 

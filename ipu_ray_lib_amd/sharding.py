@@ -27,6 +27,23 @@ def padded_count(width: int, height: int, world: int, tile_rows: int = TILE_ROWS
     return max(rank_pixels(width, height, r, world, tile_rows)[0].size for r in range(world))
 
 
+_index_cache = {}
+
+
+def _scatter_indices(width, height, world, tile_rows, device):
+    """Flat pixel index of every gathered row, rank after rank (cached: it only depends on the geometry)."""
+    import torch
+    key = (width, height, world, tile_rows, str(device))
+    if key not in _index_cache:
+        n_pad = padded_count(width, height, world, tile_rows)
+        idx = np.full((world, n_pad), -1, dtype=np.int64)
+        for r in range(world):
+            rows, cols = rank_pixels(width, height, r, world, tile_rows)
+            idx[r, : rows.size] = rows * width + cols
+        _index_cache[key] = torch.from_numpy(idx).to(device)
+    return _index_cache[key]
+
+
 def gather_frame(dist, rgb, width: int, height: int, tile_rows: int = TILE_ROWS):
     """One collective per frame. `rgb`: this rank's [n_r, 3] float32 torch tensor (any device the
     process group supports). Returns the [height, width, 3] frame on rank 0, None elsewhere."""
@@ -41,9 +58,7 @@ def gather_frame(dist, rgb, width: int, height: int, tile_rows: int = TILE_ROWS)
     dist.gather(send, bufs, dst=0)
     if rank != 0:
         return None
-    frame = torch.zeros(height, width, 3, dtype=rgb.dtype, device=rgb.device)
-    for r in range(world):
-        rows, cols = rank_pixels(width, height, r, world, tile_rows)
-        idx = torch.from_numpy(rows * width + cols).to(rgb.device)
-        frame.view(-1, 3)[idx] = bufs[r][: rows.size]
-    return frame
+    idx = _scatter_indices(width, height, world, tile_rows, rgb.device)
+    frame = torch.zeros(height * width + 1, 3, dtype=rgb.dtype, device=rgb.device)    # last row swallows the padding
+    frame[idx.reshape(-1)] = torch.stack(bufs).reshape(-1, 3)
+    return frame[:-1].view(height, width, 3)

@@ -153,6 +153,30 @@ def test_ragged_empty_and_crop(scenes):
     dev.close()
 
 
+def test_ray_batches_and_callback(scenes):
+    """--rays-per-worker / --ipu-ray-callback: the stream is traced in pipelined batches, the callback sees every
+    batch exactly once and in order, and the result is bit-identical to the single-batch render."""
+    s = scenes["box"]
+    d = s.desc
+    d.set_image(150, 101); d.samples_per_pixel = 3            # 15150 rays: ragged last batch
+    dev = irl.IpuScene(d)
+    ref = s.init_ray_stream(); dev.run(ref, irl.MODE_PATH_TRACE)
+    for batch in (4096, 1000, 15150, 20000):
+        dev.setRayBatch(batch)
+        seen = []
+        got = s.init_ray_stream()
+        dev.run(got, irl.MODE_PATH_TRACE, callback=lambda i, first, cnt: seen.append((i, first, cnt)))
+        assert rows_differing(got, ref).size == 0
+        nb = -(-got.size // min(batch, got.size))
+        assert [x[0] for x in seen] == list(range(nb))
+        assert seen[0][1] == 0 and sum(x[2] for x in seen) == got.size and all(x[1] == x[0] * min(batch, got.size) for x in seen)
+    dev.setRayBatch(2048)
+    a = s.init_ray_stream(); b = a.copy()
+    dev.run(a, irl.MODE_SHADOW_TRACE); ol.shadow_trace(d, b, 8)
+    assert_streams_identical(a, b, "batched shadow trace")
+    dev.close()
+
+
 def test_all_miss_and_arbitrary_host_rays(scenes):
     """Shadow-trace traces the caller's rays as given: rays pointing away must all escape untouched,
     random rays from inside the box must match the oracle."""
