@@ -234,6 +234,10 @@ constexpr uint32_t kLdsBudgetBytes = 160 * 1024 - 1024;     // 160 KiB per CU mi
 template <bool STATS>
 void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStream_t stream, int slot) {
   uint32_t* workCounter = S.d_workCounter + slot;
+  // raster streams (the whole window in one launch) are walked in 8x8 pixel tiles
+  const uint32_t w = (uint32_t)S.params.window_w, h = (uint32_t)S.params.window_h;
+  static const bool noTiles = getenv("MI_RAYLIB_NO_TILES") != nullptr;
+  const uint32_t tileW = (!noTiles && w >= 8 && h >= 8 && (w % 8) == 0 && (h % 8) == 0 && (uint64_t)w * h == cnt) ? w : 0u;
   HIP_CHECK(hipMemsetAsync(workCounter, 0, sizeof(uint32_t), stream));
   if (g_kernelChoice == 2 && S.ds.numNodes > 0) {
     // one 1024-thread workgroup per CU shares one LDS copy of the first nodes of the (preorder) array
@@ -243,15 +247,15 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
     static bool attrSet = false;
     if (!attrSet) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes)); attrSet = true; }
     const uint32_t blocks = std::min<uint32_t>((cnt + 1023) / 1024, 256);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, ldsNodes, g_tune);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, ldsNodes, g_tune, tileW);
   } else if (g_kernelChoice == 3 && !S.ds.hasNormals) {
     // two rays per lane, the second parked in LDS: 9 uint4 groups x 64 lanes x 4 waves = 36 KiB per workgroup
     const size_t ldsBytes = (size_t)kParkGroups * 64 * sizeof(uint4) * (256 / 64);
     const uint32_t blocks = std::min<uint32_t>((cnt + 511) / 512, 256 * 4);
-    hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, true>), dim3(blocks), dim3(256), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune);
+    hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, true>), dim3(blocks), dim3(256), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW);
   } else {
     const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, 256 * 8);
-    hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, false>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune);
+    hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, false>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW);
   }
 }
 

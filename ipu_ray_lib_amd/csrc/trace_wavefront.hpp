@@ -39,7 +39,7 @@ struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8; };
 
 template <bool STATS, bool LDS_NODES, int BLOCK, bool TWO_RAYS>
 __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : 1) path_trace_wavefront_kernel(DeviceScene sc, mi_trace_result* rays, uint32_t n,
-                                                                   uint32_t* workCounter, uint32_t ldsNodeCount, WaveTune tune) {
+                                                                   uint32_t* workCounter, uint32_t ldsNodeCount, WaveTune tune, uint32_t tileStreamW) {
   __shared__ float sinTbl[92];
   extern __shared__ __attribute__((aligned(16))) unsigned char dynLds[];
   load_sin_table(sinTbl);
@@ -123,8 +123,16 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : 1) pat
       if (ph == PH_FETCH) {
         const uint32_t idx = base + (uint32_t)__popcll(mF & ((1ull << lane) - 1ull));
         if (idx < n) {
-          pix = idx;
-          const mi_trace_result* res = rays + idx;
+          // When the stream is a raster of width tileStreamW (multiple of 8, height too), consecutive work
+          // indices walk 8x8 pixel tiles, so the 64 pixels a wave starts with are a compact tile whose
+          // primary rays traverse alike. Any order gives the same image: every pixel owns its RNG stream.
+          uint32_t entry = idx;
+          if (tileStreamW) {
+            const uint32_t t = idx >> 6, within = idx & 63u, perRow = tileStreamW >> 3;
+            entry = ((t / perRow) * 8u + (within >> 3)) * tileStreamW + (t % perRow) * 8u + (within & 7u);
+          }
+          pix = entry;
+          const mi_trace_result* res = rays + entry;
           prow = res->u; pcol = res->v;
           if (!TWO_RAYS) rgb = mk(res->rgb.x, res->rgb.y, res->rgb.z);   // TWO_RAYS accumulates rgb in memory
           rng_seed_pixel(rng, sc.rngSeed, prow, pcol);
