@@ -226,7 +226,7 @@ void ensureScratch(mi_scene& S, size_t n) {
 }
 
 bool g_fullStats = false;
-WaveTune g_tune = {5, 8, 12, 32, 2};
+WaveTune g_tune = {5, 8, 12, 32, 2, 16};
 int g_kernelChoice = 1;           // 0 = nested-loop kernel, 1 = wavefront (global nodes), 2 = wavefront + LDS-staged nodes
 
 constexpr uint32_t kLdsBudgetBytes = 160 * 1024 - 1024;     // 160 KiB per CU minus the static allocations
@@ -250,7 +250,7 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, ldsNodes, g_tune, tileW);
   } else if (g_kernelChoice == 3 && !S.ds.hasNormals) {
     // two rays per lane, the second parked in LDS: 9 uint4 groups x 64 lanes x 4 waves = 36 KiB per workgroup
-    const size_t ldsBytes = (size_t)kParkGroups * 64 * sizeof(uint4) * (256 / 64);
+    const size_t ldsBytes = (size_t)kParkBytesPerWave * (256 / 64);
     const uint32_t blocks = std::min<uint32_t>((cnt + 511) / 512, 256 * 4);
     hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, true>), dim3(blocks), dim3(256), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW);
   } else {
@@ -320,7 +320,7 @@ int mi_scene_create(const mi_scene_desc* desc, mi_scene** out) {
     S->params.mesh_normals = nullptr; S->params.mat_ids = nullptr; S->params.materials = nullptr; S->params.bvh_nodes = nullptr;
     S->params.spheres = nullptr; S->params.discs = nullptr;
     if (const char* e = getenv("MI_RAYLIB_FULL_STATS")) g_fullStats = (e[0] == '1');
-    if (const char* e = getenv("MI_RAYLIB_TUNE")) { unsigned a, b, c, dd = 32, k8 = 2; if (sscanf(e, "%u,%u,%u,%u,%u", &a, &b, &c, &dd, &k8) >= 3) g_tune = {a, b, c, dd, k8}; }
+    if (const char* e = getenv("MI_RAYLIB_TUNE")) { unsigned a, b, c, dd = 32, k8 = 2, ta = 16; if (sscanf(e, "%u,%u,%u,%u,%u,%u", &a, &b, &c, &dd, &k8, &ta) >= 3) g_tune = {a, b, c, dd, k8, ta}; }
     if (const char* e = getenv("MI_RAYLIB_KERNEL")) g_kernelChoice = (e[0] == '0') ? 0 : (e[0] == '2') ? 2 : (e[0] == '3') ? 3 : 1;
   });
   if (rc != MI_OK) { delete S; return rc; }

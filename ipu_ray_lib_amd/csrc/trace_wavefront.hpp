@@ -20,12 +20,14 @@
 
 namespace mi {
 
-// TWO_RAYS variant: every lane carries TWO pixels' state machines — one in registers
-// (active), one parked in LDS (36 dwords per lane, 9 KiB per wave). The vote counts both; before a phase
-// runs, lanes whose active ray is not in that phase but whose parked ray is swap the two (10 b128 LDS
-// writes + reads). A lane therefore takes part in a phase if EITHER of its rays is waiting for it, which
-// lifts the lanes-per-execution of every phase; the rays themselves are processed exactly as before.
+// TWO_RAYS variant: a wave owns 128 pixels' state machines — 64 in registers (one per lane,
+// "active") and 64 parked in LDS (36 dwords each, 9 KiB per wave). The vote counts both sets; before a
+// phase runs, lanes whose active ray is NOT waiting for that phase trade it for ANY parked ray that is
+// (ranks from two ballots, matched through a 64-entry LDS list, then 9 b128 LDS reads + writes). A phase
+// therefore executes with min(64, rays waiting for it among 128) lanes. The rays themselves are processed
+// exactly as before, so results are unchanged.
 constexpr uint32_t kParkGroups = 9;      // uint4 groups per parked ray
+constexpr uint32_t kParkBytesPerWave = kParkGroups * 64 * 16 + 2 * 64 * 4;   // + phase words + match list
 
 enum : uint32_t { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_GEN = 3, PH_FETCH = 4, PH_DONE = 5 };
 
@@ -35,7 +37,7 @@ enum : uint32_t { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_GEN = 3, PH_FETCH =
 //   shadeAt, genAt   top-level vote: SHADE/GEN run when their weighted population exceeds (cN+cL)*4
 //   burst    at most this many NODE/LEAF steps before the wave re-votes
 //   keep8    ... or earlier, once fewer than keep8/8 of the lanes that started the burst still traverse
-struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8; };
+struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, tradeAt; };
 
 template <bool STATS, bool LDS_NODES, int BLOCK, bool TWO_RAYS>
 __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : 1) path_trace_wavefront_kernel(DeviceScene sc, mi_trace_result* rays, uint32_t n,
@@ -66,7 +68,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : 1) pat
   Shear sh; sh.kz = 2; sh.sx = sh.sy = 0.f; sh.sz = 1.f;
   Hit hit; hit.t = kInf; hit.leaf = 0xFFFFFFFFu; hit.geomID = 0xFFFFu; hit.b0 = hit.b1 = hit.b2 = 0.f;
   uint32_t oFlags = 0, oLeaf = 0xFFFFFFFFu;   // oLeaf: leaf record of the last hit (-> primID, geomID at pixel end)
-  uint32_t phB = TWO_RAYS ? (uint32_t)PH_FETCH : (uint32_t)PH_DONE;   // phase of the ray parked in LDS
+  uint32_t phB = (uint32_t)PH_DONE;   // TWO_RAYS: phase of the ray parked in this lane's LDS slot (re-read at every vote)
   bool exactSlab = false;
   float oTmax = kInf;
   CastStats cs = {0, 0};
@@ -77,8 +79,12 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : 1) pat
 
   // Swap the register-resident ray with the parked one. Layout: group g of lane l of wave w at
   // park[(w*kParkGroups + g)*64 + l] (uint4): consecutive lanes 16 B apart, conflict-free b128 accesses.
-  uint4* park = reinterpret_cast<uint4*>(dynLds) + (size_t)(threadIdx.x >> 6) * kParkGroups * 64 + lane;
-  auto swapRays = [&]() {
+  unsigned char* waveLds = dynLds + (size_t)(threadIdx.x >> 6) * kParkBytesPerWave;
+  uint4* parkBase = reinterpret_cast<uint4*>(waveLds);
+  volatile uint32_t* pph = reinterpret_cast<volatile uint32_t*>(waveLds + kParkGroups * 64 * 16);   // phase of parked slot j
+  volatile uint32_t* cq = pph + 64;                                                                  // rank -> slot match list
+  auto swapRays = [&](uint32_t slot) {
+    uint4* park = parkBase + slot;
     auto fu = [](float f) { return __float_as_uint(f); };
     auto uf = [](uint32_t u) { return __uint_as_float(u); };
     const uint32_t packed = ph | (bounce << 3) | (oFlags << 11) | (sh.kz << 13) | ((exactSlab ? 1u : 0u) << 15);
@@ -106,11 +112,32 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : 1) pat
     const uint32_t pk = r8.y;
     ph = pk & 7u; bounce = (pk >> 3) & 0xFFu; oFlags = (pk >> 11) & 3u; sh.kz = (pk >> 13) & 3u; exactSlab = ((pk >> 15) & 1u) != 0;
   };
+  // Trade (TWO_RAYS): lanes whose active ray does not wait for the wanted phase(s) take any parked ray that
+  // does. Returns the number of rays traded. phB must hold the current phase of this lane's parked slot.
+  auto trade = [&](bool wantT, uint32_t want) -> uint32_t {
+    const bool isFree = wantT ? (ph != PH_NODE && ph != PH_LEAF) : (ph != want);
+    const bool parkedReady = wantT ? (phB == PH_NODE || phB == PH_LEAF) : (phB == want);
+    const unsigned long long mFree = __ballot(isFree), mReady = __ballot(parkedReady);
+    const uint32_t m = min((uint32_t)__popcll(mFree), (uint32_t)__popcll(mReady));
+    if (m > 0) {
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      if (parkedReady) { const uint32_t r = (uint32_t)__popcll(mReady & lt); if (r < m) cq[r] = lane; }
+      __builtin_amdgcn_wave_barrier();
+      if (isFree) {
+        const uint32_t r = (uint32_t)__popcll(mFree & lt);
+        if (r < m) { const uint32_t j = cq[r]; const uint32_t t = ph; swapRays(j); pph[j] = t; }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    return m;
+  };
   if (TWO_RAYS) {
     // park an initial FETCH-state ray so that the first swap brings in a ray that asks for a pixel
     ph = PH_FETCH;
-    swapRays();           // registers <- uninitialised LDS (ignored: overwritten below), LDS <- FETCH-state ray
+    swapRays(lane);       // registers <- uninitialised LDS (ignored: overwritten below), LDS <- FETCH-state ray
+    pph[lane] = PH_FETCH;
     ph = PH_FETCH; bounce = 0; oFlags = 0; sh.kz = 2; exactSlab = false; hit.leaf = 0xFFFFFFFFu; oLeaf = 0xFFFFFFFFu;
+    __builtin_amdgcn_wave_barrier();
   }
 
   for (;;) {
@@ -145,33 +172,34 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : 1) pat
     }
 
     // ---------------- vote ----------------
-    uint32_t cN = (uint32_t)__popcll(__ballot(ph == PH_NODE || (TWO_RAYS && phB == PH_NODE)));
-    uint32_t cL = (uint32_t)__popcll(__ballot(ph == PH_LEAF || (TWO_RAYS && phB == PH_LEAF)));
-    uint32_t cS = (uint32_t)__popcll(__ballot(ph == PH_SHADE || (TWO_RAYS && phB == PH_SHADE)));
-    uint32_t cG = (uint32_t)__popcll(__ballot(ph == PH_GEN || (TWO_RAYS && phB == PH_GEN)));
-    if (TWO_RAYS && __ballot(phB == PH_FETCH && ph != PH_FETCH)) {
-      // a parked ray still waits for its first pixel: bring it in, the FETCH service at the loop top serves it
-      if (phB == PH_FETCH && ph != PH_FETCH) { const uint32_t t = ph; swapRays(); phB = t; }
-      continue;
+    if (TWO_RAYS) phB = pph[lane];
+    uint32_t cN = (uint32_t)__popcll(__ballot(ph == PH_NODE)), cL = (uint32_t)__popcll(__ballot(ph == PH_LEAF));
+    uint32_t cS = (uint32_t)__popcll(__ballot(ph == PH_SHADE)), cG = (uint32_t)__popcll(__ballot(ph == PH_GEN));
+    uint32_t tN = cN, tL = cL, tS = cS, tG = cG;          // populations incl. parked rays
+    if (TWO_RAYS) {
+      if (__ballot(phB == PH_FETCH && ph != PH_FETCH)) {
+        // a parked ray still waits for its first pixel: bring it in, the FETCH service at the loop top serves it
+        if (phB == PH_FETCH && ph != PH_FETCH) { const uint32_t t = ph; swapRays(lane); pph[lane] = t; }
+        __builtin_amdgcn_wave_barrier();
+        continue;
+      }
+      tN += (uint32_t)__popcll(__ballot(phB == PH_NODE)); tL += (uint32_t)__popcll(__ballot(phB == PH_LEAF));
+      tS += (uint32_t)__popcll(__ballot(phB == PH_SHADE)); tG += (uint32_t)__popcll(__ballot(phB == PH_GEN));
     }
-    if ((cN | cL | cS | cG) == 0) break;            // every ray DONE (FETCH lanes were just served)
+    if ((tN | tL | tS | tG) == 0) break;            // every ray DONE (FETCH lanes were just served)
     // Top-level vote: TRAVERSE (the NODE and LEAF populations together) against SHADE and GEN, by weighted
-    // population. Inside TRAVERSE a two-way mini-vote (two ballots) alternates box tests and primitive
-    // tests, so the expensive 4-way vote is only paid when the wave leaves traversal.
-    // run: 0 = TRAVERSE, 2 = SHADE, 3 = GEN; with TWO_RAYS the first phase of the traversal is also a swap point.
+    // population (a phase cannot use more than 64 lanes). Inside TRAVERSE a two-way mini-vote (two ballots)
+    // alternates box tests and primitive tests, so the expensive vote is only paid when the wave leaves traversal.
+    // run: 0 = TRAVERSE, 2 = SHADE, 3 = GEN
     uint32_t run;
     {
-      const uint32_t wT = (cN + cL) * 4u, wS = cS * tune.shadeAt, wG = cG * tune.genAt;
-      if ((cN + cL) > 0 && wT >= max(wS, wG)) run = 0;
+      const uint32_t pT = min(tN + tL, 64u), pS = min(tS, 64u), pG = min(tG, 64u);
+      const uint32_t wT = pT * 4u, wS = pS * tune.shadeAt, wG = pG * tune.genAt;
+      if (pT > 0 && wT >= max(wS, wG)) run = 0;
       else run = (wS >= wG) ? 2 : 3;
     }
     if (TWO_RAYS) {
-      const bool wantT = run == 0;
-      const uint32_t want = run == 2 ? (uint32_t)PH_SHADE : (uint32_t)PH_GEN;
-      const bool needSwap = wantT ? ((ph != PH_NODE && ph != PH_LEAF) && (phB == PH_NODE || phB == PH_LEAF)) : (ph != want && phB == want);
-      if (__ballot(needSwap)) {
-        if (needSwap) { const uint32_t t = ph; swapRays(); phB = t; }
-      }
+      trade(run == 0, run == 2 ? (uint32_t)PH_SHADE : (uint32_t)PH_GEN);
       cN = (uint32_t)__popcll(__ballot(ph == PH_NODE)); cL = (uint32_t)__popcll(__ballot(ph == PH_LEAF));
       cS = (uint32_t)__popcll(__ballot(ph == PH_SHADE)); cG = (uint32_t)__popcll(__ballot(ph == PH_GEN));
     }
@@ -250,6 +278,14 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : 1) pat
         }
         cN = (uint32_t)__popcll(__ballot(ph == PH_NODE));
         cL = (uint32_t)__popcll(__ballot(ph == PH_LEAF));
+        if (TWO_RAYS && 64u - (cN + cL) >= tune.tradeAt) {
+          // enough idle lanes: refill them from the parked rays that are mid-traversal
+          phB = pph[lane];
+          if ((uint32_t)__popcll(__ballot(phB == PH_NODE || phB == PH_LEAF)) >= tune.tradeAt / 2u && trade(true, 0u) > 0) {
+            cN = (uint32_t)__popcll(__ballot(ph == PH_NODE));
+            cL = (uint32_t)__popcll(__ballot(ph == PH_LEAF));
+          }
+        }
         if (++steps >= tune.burst || (cN + cL) * 8u < startT * tune.keep8 || (cN + cL) == 0) break;
       }
       if (STATS) tTrav += __builtin_amdgcn_s_memtime() - tq0;
