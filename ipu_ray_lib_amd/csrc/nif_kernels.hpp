@@ -93,7 +93,8 @@ struct NifDevice {
     NifParams P{};
     P.numLayers = numLayers; P.embedDim = embedDim; P.featBase = featBase;
     const uint32_t kPadMax = ((featBase + F + 31u) & ~31u);
-    P.stride = kPadMax + 8;                       // +8 halves: consecutive rows start 4 banks apart
+    P.stride = kPadMax + 16;                      // +16 halves: rows start 8 banks apart -> the ds_read_b128 lane groups
+                                                  // (rows l&15, k-chunk l>>4) hit 16 disjoint 4-bank slots (measured: +8 gave 2-way conflicts)
     P.maxValue = maxValue; P.mean[0] = mean[0]; P.mean[1] = mean[1]; P.mean[2] = mean[2]; P.logTonemap = logTonemap;
     std::vector<_Float16> packed;
     std::vector<float> bias;
