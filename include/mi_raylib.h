@@ -164,7 +164,7 @@ int mi_reset_counters(mi_scene* scene);
 int mi_get_phase_stats(mi_scene* scene, uint64_t stats[12]);
 
 /* Replaces: IpuScene::loadNifModel (src/IpuScene.cpp:174-187) with the weights handed over as
- * arrays (the reference's Keras-H5 file loader is out of scope).
+ * arrays (the file side — nif_metadata.txt + Keras-H5 — is mi_host_nif_load in mi_scene_host.h).
  * Dense layer i has kernel[i] of shape [rows[i] x cols[i]] row-major (Keras kernel:0 layout,
  * y = x·W + b) and bias[i] of cols[i] floats (NULL = no bias); relu[i] != 0 applies ReLU.
  * Where a layer's rows != current activation width, the Fourier features are re-concatenated

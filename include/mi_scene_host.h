@@ -58,6 +58,39 @@ int mi_init_ray_stream(const mi_scene_desc* desc, mi_trace_result* rays, size_t 
 /* scaleRgb (src/app_utils.cpp:55-59) */
 void mi_scale_rgb(mi_trace_result* rays, size_t n, float scale);
 
+/* ---- NIF assets ----------------------------------------------------------------
+ * IpuScene::loadNifModel(assetPath) (src/IpuScene.cpp:174-187) reads <assetPath>/nif_metadata.txt
+ * (NifMetaData.cpp:11-71) and <assetPath>/converted.hdf5, a Keras "Functional" model whose Dense layers
+ * are stored under /model_weights/<layer>/<layer>/{kernel:0,bias:0} as float16 or float32
+ * (src/keras/Hdf5Model.cpp:62-133). mi_host_nif_load does the same and hands the layers back in the
+ * form mi_scene_set_nif takes (binary32 arrays; binary16 weights are widened exactly). HDF5 is reached
+ * through the plugin libmi_nif_h5.so next to this library; if <assetPath>/converted.hdf5 is absent,
+ * <assetPath>/nif_weights.bin is read instead: u32 numLayers, then per layer u32 rows, u32 cols,
+ * u8 relu, u8 hasBias, f32 kernel[rows*cols] (Keras kernel:0 order), f32 bias[cols] if hasBias. */
+typedef struct mi_host_nif mi_host_nif;
+
+typedef struct mi_nif_desc {
+  uint32_t num_layers;
+  const float* const* kernels;   /* [num_layers] -> rows[i]*cols[i] floats, row-major */
+  const float* const* biases;    /* [num_layers] -> cols[i] floats or NULL */
+  const uint32_t* rows;
+  const uint32_t* cols;
+  const uint8_t* relu;           /* activation "relu" -> 1, "linear" -> 0 (NifModel.cpp:75-77, 324) */
+  uint32_t embedding_dimension;  /* nif_metadata.txt */
+  uint32_t hidden_size;          /* argument after --layer-size in train_command (0 if absent) */
+  float max_value;
+  float mean[3];                 /* eps already folded in when log_tonemap (NifMetaData.cpp:48-53) */
+  int32_t log_tonemap;
+  int32_t weights_are_half;      /* any kernel stored as float16 */
+  const char* name;
+  const char* source;            /* the weights file that was read */
+} mi_nif_desc;
+
+int mi_host_nif_load(const char* asset_path, mi_host_nif** out);
+int mi_host_nif_describe(const mi_host_nif* nif, mi_nif_desc* desc);   /* pointers valid until destroy */
+void mi_host_nif_destroy(mi_host_nif* nif);
+const char* mi_host_nif_last_error(void);
+
 const char* mi_host_last_error(void);
 
 #ifdef __cplusplus

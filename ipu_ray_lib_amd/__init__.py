@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -85,6 +86,16 @@ class SceneDesc(C.Structure):
         return int(self.window_w) * int(self.window_h)
 
 
+class NifDesc(C.Structure):
+    """mi_nif_desc (include/mi_scene_host.h)."""
+    _fields_ = [("num_layers", C.c_uint32), ("kernels", C.POINTER(C.POINTER(C.c_float))),
+                ("biases", C.POINTER(C.POINTER(C.c_float))), ("rows", C.POINTER(C.c_uint32)),
+                ("cols", C.POINTER(C.c_uint32)), ("relu", C.POINTER(C.c_uint8)),
+                ("embedding_dimension", C.c_uint32), ("hidden_size", C.c_uint32), ("max_value", C.c_float),
+                ("mean", C.c_float * 3), ("log_tonemap", C.c_int32), ("weights_are_half", C.c_int32),
+                ("name", C.c_char_p), ("source", C.c_char_p)]
+
+
 class RaylibError(RuntimeError):
     pass
 
@@ -116,6 +127,11 @@ def host_lib() -> C.CDLL:
         lib.mi_init_ray_stream.argtypes = [C.POINTER(SceneDesc), C.c_void_p, C.c_size_t]
         lib.mi_scale_rgb.argtypes = [C.c_void_p, C.c_size_t, C.c_float]
         lib.mi_scale_rgb.restype = None
+        lib.mi_host_nif_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        lib.mi_host_nif_describe.argtypes = [C.c_void_p, C.POINTER(NifDesc)]
+        lib.mi_host_nif_destroy.argtypes = [C.c_void_p]
+        lib.mi_host_nif_destroy.restype = None
+        lib.mi_host_nif_last_error.restype = C.c_char_p
         _host = lib
     return _host
 
@@ -253,6 +269,37 @@ class HostScene:
             pass
 
 
+class NifAssets:
+    """NIF model read from an 'assets.extra' directory: nif_metadata.txt + converted.hdf5 (Keras H5) or
+    nif_weights.bin — what IpuScene::loadNifModel reads (src/IpuScene.cpp:174-187). Arrays are copies."""
+
+    def __init__(self, asset_path):
+        lib = host_lib()
+        h = C.c_void_p()
+        if lib.mi_host_nif_load(os.fspath(asset_path).encode(), C.byref(h)) != 0:
+            raise RaylibError(lib.mi_host_nif_last_error().decode())
+        try:
+            d = NifDesc()
+            if lib.mi_host_nif_describe(h, C.byref(d)) != 0:
+                raise RaylibError(lib.mi_host_nif_last_error().decode())
+            self.kernels, self.biases, self.relu = [], [], []
+            for i in range(d.num_layers):
+                r, c = int(d.rows[i]), int(d.cols[i])
+                self.kernels.append(np.ctypeslib.as_array(d.kernels[i], shape=(r, c)).copy())
+                self.biases.append(np.ctypeslib.as_array(d.biases[i], shape=(c,)).copy() if d.biases[i] else None)
+                self.relu.append(bool(d.relu[i]))
+            self.embedding_dimension = int(d.embedding_dimension)
+            self.hidden_size = int(d.hidden_size)
+            self.max_value = float(d.max_value)
+            self.mean = np.array(list(d.mean), dtype=np.float32)
+            self.log_tonemap = bool(d.log_tonemap)
+            self.weights_are_half = bool(d.weights_are_half)
+            self.name = d.name.decode()
+            self.source = d.source.decode()
+        finally:
+            lib.mi_host_nif_destroy(h)
+
+
 class IpuScene:
     """Mirror of the reference's ``IpuScene`` driver object (include/IpuScene.hpp:22-56) over the
     C ABI: construct from a scene description, optionally load a NIF, ``run`` a ray stream."""
@@ -276,8 +323,18 @@ class IpuScene:
     def getTraceTimeSecs(self) -> float:
         return float(self._lib.mi_trace_time_secs(self._h))
 
+    def loadNifModel(self, asset_path) -> bool:
+        """IpuScene::loadNifModel (src/IpuScene.cpp:174-187): log and return False on any failure."""
+        try:
+            a = NifAssets(asset_path)
+            self.setNif(a.kernels, a.biases, a.relu, a.embedding_dimension, a.max_value, a.mean, a.log_tonemap)
+            return True
+        except RaylibError as e:
+            print(f"[error] {e}", file=sys.stderr)
+            return False
+
     def setNif(self, kernels, biases, relu, embedding_dimension, max_value, mean, log_tonemap=True):
-        """Weights as arrays (the Keras-H5 loader of loadNifModel is a 'next' row)."""
+        """Weights as arrays (what loadNifModel ends up calling)."""
         n = len(kernels)
         ks = [np.ascontiguousarray(k, dtype=np.float32) for k in kernels]
         bs = [None if b is None else np.ascontiguousarray(b, dtype=np.float32) for b in biases]

@@ -8,14 +8,12 @@
 
 #include <cstdio>
 #include <cstdlib>
-#include <fstream>
 #include <functional>
-#include <sstream>
 #include <string>
 #include <vector>
 
 #include "../../../include/mi_raylib.h"
-#include "json_min.hpp"
+#include "../../../include/mi_scene_host.h"
 
 namespace mi {
 
@@ -40,51 +38,29 @@ class IpuScene {
     data.spheres = spheres.data(); data.num_spheres = (uint32_t)spheres.size();
     data.discs = discs.data(); data.num_discs = (uint32_t)discs.size();
   }
-  ~IpuScene() { if (scene) mi_scene_destroy(scene); }
+  ~IpuScene() { if (scene) mi_scene_destroy(scene); if (nif) mi_host_nif_destroy(nif); }
   IpuScene(const IpuScene&) = delete;
   IpuScene& operator=(const IpuScene&) = delete;
 
   void setRuntimeConfig(const RuntimeConfig& c) { config = c; }
 
-  // Reference: reads <assetPath>/nif_metadata.txt and <assetPath>/converted.hdf5. The Keras-H5 reader
-  // is not reproduced; weights are read from <assetPath>/nif_weights.bin instead:
-  // u32 numLayers, then per layer u32 rows, u32 cols, u8 relu, u8 hasBias, f32 kernel[rows*cols]
-  // (row-major, Keras kernel:0 order), f32 bias[cols]. Returns false (after logging) on any failure,
-  // exactly like the reference (src/IpuScene.cpp:174-187).
+  // Reference: reads <assetPath>/nif_metadata.txt and <assetPath>/converted.hdf5 (src/IpuScene.cpp:174-187).
+  // Same here, through libmi_scene_host.so (mi_host_nif_load: Keras-H5 via the HDF5 plugin, or the flat
+  // nif_weights.bin dump when no .hdf5 is present). Returns false (after logging) on any failure,
+  // exactly like the reference.
   bool loadNifModel(const std::string& assetPath) {
-    try {
-      std::ifstream meta(assetPath + "/nif_metadata.txt");
-      if (!meta) throw std::runtime_error("cannot open nif_metadata.txt");
-      std::stringstream ss; ss << meta.rdbuf();
-      auto doc = json::parse(ss.str());
-      nifEmbedding = (uint32_t)doc->at("embedding_dimension").number();
-      const auto& enc = doc->at("encode_params");
-      const float eps = (float)enc.at("eps").number();
-      nifLogTonemap = enc.at("log_tone_map").b;
-      nifMax = (float)enc.at("max").number();
-      for (int i = 0; i < 3; ++i) nifMean[i] = (float)enc.at("mean").at(i).number();
-      if (nifLogTonemap) for (float& m : nifMean) m -= eps;            // NifMetaData.cpp:48-53
-      std::ifstream w(assetPath + "/nif_weights.bin", std::ios::binary);
-      if (!w) throw std::runtime_error("cannot open nif_weights.bin (the reference's converted.hdf5 is not readable here)");
-      uint32_t n = 0; w.read((char*)&n, 4);
-      if (!w || n == 0 || n > 16) throw std::runtime_error("bad layer count");
-      nifKernels.assign(n, {}); nifBiases.assign(n, {}); nifRows.assign(n, 0); nifCols.assign(n, 0); nifRelu.assign(n, 0);
-      for (uint32_t l = 0; l < n; ++l) {
-        uint8_t relu = 0, hasBias = 0;
-        w.read((char*)&nifRows[l], 4); w.read((char*)&nifCols[l], 4); w.read((char*)&relu, 1); w.read((char*)&hasBias, 1);
-        nifRelu[l] = relu;
-        nifKernels[l].resize((size_t)nifRows[l] * nifCols[l]);
-        w.read((char*)nifKernels[l].data(), nifKernels[l].size() * 4);
-        if (hasBias) { nifBiases[l].resize(nifCols[l]); w.read((char*)nifBiases[l].data(), nifCols[l] * 4); }
-        if (!w) throw std::runtime_error("truncated weights file");
-      }
-      nifLoaded = true;
-      std::fprintf(stderr, "[info] Loaded NIF model from '%s'\n", assetPath.c_str());
-      return true;
-    } catch (const std::exception& e) {
-      std::fprintf(stderr, "[error] Could not load NIF model from '%s'. Exception: %s\n", assetPath.c_str(), e.what());
+    mi_host_nif* loaded = nullptr;
+    if (mi_host_nif_load(assetPath.c_str(), &loaded) != 0) {
+      std::fprintf(stderr, "[error] %s\n", mi_host_nif_last_error());
+      return false;
     }
-    return false;
+    if (nif) mi_host_nif_destroy(nif);
+    nif = loaded;
+    mi_nif_desc d{};
+    mi_host_nif_describe(nif, &d);
+    std::fprintf(stderr, "[info] Loaded NIF model '%s' from '%s' (%u layers, %s weights)\n", d.name, d.source, d.num_layers,
+                 d.weights_are_half ? "float16" : "float32");
+    return true;
   }
 
   void setHdriRotation(float degrees) { hdriRotationDegrees = degrees; }
@@ -97,11 +73,11 @@ class IpuScene {
   int run() {
     data.device = config.device;
     if (mi_scene_create(&data, &scene) != MI_OK) return fail("scene creation");
-    if (nifLoaded) {
-      std::vector<const float*> kp, bp;
-      for (size_t l = 0; l < nifKernels.size(); ++l) { kp.push_back(nifKernels[l].data()); bp.push_back(nifBiases[l].empty() ? nullptr : nifBiases[l].data()); }
-      if (mi_scene_set_nif(scene, (uint32_t)kp.size(), kp.data(), bp.data(), nifRows.data(), nifCols.data(), nifRelu.data(),
-                           nifEmbedding, nifMax, nifMean, nifLogTonemap ? 1 : 0) != MI_OK) return fail("NIF upload");
+    if (nif) {
+      mi_nif_desc d{};
+      mi_host_nif_describe(nif, &d);
+      if (mi_scene_set_nif(scene, d.num_layers, d.kernels, d.biases, d.rows, d.cols, d.relu, d.embedding_dimension,
+                           d.max_value, d.mean, d.log_tonemap) != MI_OK) return fail("NIF upload");
     }
     mi_scene_set_hdri_rotation(scene, hdriRotationDegrees);
     mi_scene_set_max_nif_batch(scene, nifMaxRaysPerBatch);
@@ -136,12 +112,7 @@ class IpuScene {
   double traceTimeSecs = 0.0;
   float hdriRotationDegrees = 0.f;
   std::size_t nifMaxRaysPerBatch = 0;
-  bool nifLoaded = false, nifLogTonemap = true;
-  uint32_t nifEmbedding = 0;
-  float nifMax = 1.f, nifMean[3] = {0, 0, 0};
-  std::vector<std::vector<float>> nifKernels, nifBiases;
-  std::vector<uint32_t> nifRows, nifCols;
-  std::vector<uint8_t> nifRelu;
+  mi_host_nif* nif = nullptr;
 };
 
 }  // namespace mi

@@ -43,7 +43,7 @@ const char* kHelp =
     "  --anti-alias arg (=0.25)            Width of anti-aliasing noise distribution in pixels.\n"
     "  --mesh-file arg                     A Collada (.dae) scene with camera to render instead of a built-in scene, or the\n"
     "                                      glTF-binary mesh placed in the built-in box scene (default assets/monkey_bust.glb).\n"
-    "  --nif-hdri arg                      Path to the 'assets.extra' directory of a NIF model (nif_metadata.txt + nif_weights.bin).\n"
+    "  --nif-hdri arg                      Path to the 'assets.extra' directory of a NIF model (nif_metadata.txt + converted.hdf5 | nif_weights.bin).\n"
     "  --hdri-rotation arg (=0)            Azimuthal rotation for HDRI environment map (degrees).\n"
     "  --load-normals                      Load (and interpolate) vertex normals of a mesh file.\n"
     "  --scene arg (=box)                  One of the built in scenes [box-simple, box, spheres].\n"

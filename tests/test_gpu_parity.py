@@ -466,3 +466,33 @@ def test_nif_path_trace_against_oracle(scenes):
     err = np.abs(g - w) / (np.abs(w) + 0.05)
     assert np.quantile(err, 0.995) < 0.02 and err.max() < 0.2, (np.quantile(err, 0.995), err.max())
     dev.close()
+
+
+def test_loadNifModel_keras_h5_against_oracle(scenes):
+    """loadNifModel on the committed Keras-H5 fixture (binary16 kernels, a bias-free layer, widths 32/48/3:
+    the generic MLP path) and the same weights handed to the oracle. Tolerance as test_nif_mlp_against_oracle."""
+    import torch
+    from pathlib import Path
+    golden = Path(__file__).resolve().parent / "golden" / "nif_tiny"
+    if not (irl.PKG_DIR / "libmi_nif_h5.so").exists():
+        pytest.skip("HDF5 plugin not built")
+    a = irl.NifAssets(golden)
+    dev = irl.IpuScene(scenes["spheres"].desc)
+    assert dev.loadNifModel(golden)
+    assert not dev.loadNifModel(golden / "does_not_exist")       # logs and returns False, model unchanged
+    rng = np.random.default_rng(11)
+    n = 4099
+    u = rng.random(n).astype(np.float32); v = rng.random(n).astype(np.float32)
+    du, dv = torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda()
+    out = torch.zeros(n, 3, device="cuda")
+    dev.nif_infer_device(du.data_ptr(), dv.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    nif, keep = ol.make_nif(a.kernels, a.biases, a.relu, a.embedding_dimension, a.max_value, a.mean, a.log_tonemap,
+                            half_features=True, half_weights_acts=True)
+    want = np.zeros((n, 3), np.float32)
+    ol.lib().o_nif_infer(C.byref(nif), u.ctypes.data, v.ctypes.data, n, want.ctypes.data)
+    assert np.isfinite(got).all()
+    err = np.abs(got - want) / (np.abs(want) + 1e-3 / 0.02)
+    assert np.quantile(err, 0.999) < 0.02 and err.max() < 0.10, (np.quantile(err, 0.999), err.max())
+    dev.close()
