@@ -125,6 +125,14 @@ enum { MI_MODE_SHADOW_TRACE = 0, MI_MODE_PATH_TRACE = 1 };
 /* Replaces: IpuScene::IpuScene(...) + setRuntimeConfig (src/IpuScene.cpp:24-62, trace.cpp:297-309) */
 int mi_scene_create(const mi_scene_desc* desc, mi_scene** out);
 
+/* Same, from the reference's serialised scene: `blob` is the byte stream Serialiser<16> produced for the
+ * SceneRef (IpuScene's `serialiser.bytes`, src/IpuScene.cpp:51-53; format in csrc/scene_blob.hpp), i.e.
+ * what the reference broadcasts to every tile (src/IpuScene.cpp:200-216, 422-426). The eight arrays and
+ * maxLeafDepth..samplesPerPixel are taken from the blob; spheres/discs, rng_seed, the crop window,
+ * path_trace and device from `extras` (whose array fields are ignored). The bytes are validated like any
+ * other scene and copied; no alignment requirement. */
+int mi_scene_create_from_blob(const uint8_t* blob, size_t size, const mi_scene_desc* extras, mi_scene** out);
+
 /* Replaces: IpuScene::~IpuScene */
 void mi_scene_destroy(mi_scene* scene);
 

@@ -58,6 +58,24 @@ int mi_init_ray_stream(const mi_scene_desc* desc, mi_trace_result* rays, size_t 
 /* scaleRgb (src/app_utils.cpp:55-59) */
 void mi_scale_rgb(mi_trace_result* rays, size_t n, float scale);
 
+/* ---- serialised scene -----------------------------------------------------------
+ * The byte stream the reference's Serialiser<16> writes for a SceneRef (include/serialisation/
+ * serialisation.hpp:33-53, src/IpuScene.cpp:51-53) and Deserialiser<16> aliases in place
+ * (deserialisation.hpp:43-59). Layout is documented in ipu_ray_lib_amd/csrc/scene_blob.hpp. The blob
+ * carries the eight scene arrays and maxLeafDepth .. samplesPerPixel; spheres, discs, rng seed, crop
+ * window, pathTrace and device are not part of it.
+ *   mi_scene_blob_size      bytes mi_scene_serialise will write for `desc`
+ *   mi_scene_serialise      writes the blob; MI-host error if capacity is too small
+ *   mi_scene_deserialise    fills `desc`'s array pointers with views INTO `blob` (which must be 16-byte
+ *                           aligned and outlive the desc) and the eight scalars; other fields untouched.
+ *                           A truncated blob fails with "Deserialiser encountered end of byte stream." */
+size_t mi_scene_blob_size(const mi_scene_desc* desc);
+int mi_scene_serialise(const mi_scene_desc* desc, uint8_t* out, size_t capacity, size_t* written);
+int mi_scene_deserialise(const uint8_t* blob, size_t size, mi_scene_desc* desc, size_t* consumed);
+/* Padding the format inserts before an object of alignment `align` at byte offset `offset`
+ * (Serialiser::calculatePadding, Serialiser.hpp:30-39). */
+uint32_t mi_blob_padding(uint32_t base_align, size_t offset, uint32_t align);
+
 /* ---- NIF assets ----------------------------------------------------------------
  * IpuScene::loadNifModel(assetPath) (src/IpuScene.cpp:174-187) reads <assetPath>/nif_metadata.txt
  * (NifMetaData.cpp:11-71) and <assetPath>/converted.hdf5, a Keras "Functional" model whose Dense layers

@@ -127,6 +127,12 @@ def host_lib() -> C.CDLL:
         lib.mi_init_ray_stream.argtypes = [C.POINTER(SceneDesc), C.c_void_p, C.c_size_t]
         lib.mi_scale_rgb.argtypes = [C.c_void_p, C.c_size_t, C.c_float]
         lib.mi_scale_rgb.restype = None
+        lib.mi_scene_blob_size.argtypes = [C.POINTER(SceneDesc)]
+        lib.mi_scene_blob_size.restype = C.c_size_t
+        lib.mi_scene_serialise.argtypes = [C.POINTER(SceneDesc), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        lib.mi_scene_deserialise.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(SceneDesc), C.POINTER(C.c_size_t)]
+        lib.mi_blob_padding.argtypes = [C.c_uint32, C.c_size_t, C.c_uint32]
+        lib.mi_blob_padding.restype = C.c_uint32
         lib.mi_host_nif_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
         lib.mi_host_nif_describe.argtypes = [C.c_void_p, C.POINTER(NifDesc)]
         lib.mi_host_nif_destroy.argtypes = [C.c_void_p]
@@ -151,6 +157,7 @@ def device_lib() -> C.CDLL:
         lib.mi_last_error.restype = C.c_char_p
         lib.mi_version.restype = C.c_char_p
         lib.mi_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
+        lib.mi_scene_create_from_blob.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
         lib.mi_scene_destroy.argtypes = [C.c_void_p]
         lib.mi_scene_destroy.restype = None
         lib.mi_render.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
@@ -269,6 +276,34 @@ class HostScene:
             pass
 
 
+def aligned_bytes(n: int, align: int = 16) -> np.ndarray:
+    """A writable uint8 array of n bytes whose first byte is `align`-aligned."""
+    raw = np.zeros(n + align, np.uint8)
+    off = (-raw.ctypes.data) % align
+    return raw[off:off + n]
+
+
+def serialise_scene(desc: SceneDesc) -> np.ndarray:
+    """Serialiser<16> << SceneRef (src/IpuScene.cpp:51-53): the scene as one 16-byte-aligned byte stream."""
+    lib = host_lib()
+    n = lib.mi_scene_blob_size(C.byref(desc))
+    out = aligned_bytes(n)
+    written = C.c_size_t()
+    _check_host(lib.mi_scene_serialise(C.byref(desc), out.ctypes.data, n, C.byref(written)))
+    assert written.value == n
+    return out
+
+
+def deserialise_scene(blob: np.ndarray, into: SceneDesc | None = None) -> SceneDesc:
+    """Deserialiser<16> >> SceneRef: array views INTO `blob` (keep it alive) + the eight scalars."""
+    d = into if into is not None else SceneDesc()
+    used = C.c_size_t()
+    _check_host(host_lib().mi_scene_deserialise(blob.ctypes.data, blob.size, C.byref(d), C.byref(used)))
+    d._blob = blob        # keep-alive
+    d._blob_bytes_used = used.value
+    return d
+
+
 class NifAssets:
     """NIF model read from an 'assets.extra' directory: nif_metadata.txt + converted.hdf5 (Keras H5) or
     nif_weights.bin — what IpuScene::loadNifModel reads (src/IpuScene.cpp:174-187). Arrays are copies."""
@@ -311,6 +346,17 @@ class IpuScene:
         _check_dev(self._lib.mi_scene_create(C.byref(desc), C.byref(self._h)))
 
     # -- reference API names -------------------------------------------------------------
+    @classmethod
+    def from_blob(cls, blob: np.ndarray, extras: SceneDesc) -> "IpuScene":
+        """Scene from the reference's serialised byte stream + the fields that are not part of it."""
+        self = cls.__new__(cls)
+        self._lib = device_lib()
+        self._h = C.c_void_p()
+        self.desc = extras
+        b = np.ascontiguousarray(blob, dtype=np.uint8)
+        _check_dev(self._lib.mi_scene_create_from_blob(b.ctypes.data, b.size, C.byref(extras), C.byref(self._h)))
+        return self
+
     def setHdriRotation(self, degrees: float):
         _check_dev(self._lib.mi_scene_set_hdri_rotation(self._h, float(degrees)))
 

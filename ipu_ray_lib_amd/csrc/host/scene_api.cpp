@@ -6,6 +6,7 @@
 
 #include "../../../include/mi_scene_host.h"
 #include "scene_types.hpp"
+#include "../scene_blob.hpp"
 
 using namespace mi;
 using namespace mi::host;
@@ -162,6 +163,37 @@ int mi_init_ray_stream(const mi_scene_desc* d, mi_trace_result* rays, size_t cap
 
 void mi_scale_rgb(mi_trace_result* rays, size_t n, float scale) {
   for (size_t i = 0; i < n; ++i) { rays[i].rgb.x *= scale; rays[i].rgb.y *= scale; rays[i].rgb.z *= scale; }
+}
+
+size_t mi_scene_blob_size(const mi_scene_desc* d) {
+  if (!d) return 0;
+  mi::blob::Writer w(16);
+  mi::blob::serialiseScene(w, *d);
+  return w.bytes.size();
+}
+
+int mi_scene_serialise(const mi_scene_desc* d, uint8_t* out, size_t capacity, size_t* written) {
+  return guarded([&] {
+    if (!d || !out) throw std::runtime_error("null argument");
+    mi::blob::Writer w(16, 600 * 1024);                            // the reference reserves 600 KiB (src/IpuScene.cpp:31)
+    mi::blob::serialiseScene(w, *d);
+    if (w.bytes.size() > capacity) throw std::runtime_error("serialised scene needs " + std::to_string(w.bytes.size()) + " bytes");
+    std::memcpy(out, w.bytes.data(), w.bytes.size());
+    if (written) *written = w.bytes.size();
+  });
+}
+
+int mi_scene_deserialise(const uint8_t* blob, size_t size, mi_scene_desc* d, size_t* consumed) {
+  return guarded([&] {
+    if (!blob || !d) throw std::runtime_error("null argument");
+    if ((uintptr_t)blob % 16) throw std::runtime_error("serialised scene must be 16-byte aligned to be aliased in place");
+    const size_t used = mi::blob::deserialiseScene(blob, size, *d, 16);
+    if (consumed) *consumed = used;
+  });
+}
+
+uint32_t mi_blob_padding(uint32_t base_align, size_t offset, uint32_t align) {
+  return align ? mi::blob::padding(base_align, offset, align) : 0u;
 }
 
 }  // extern "C"

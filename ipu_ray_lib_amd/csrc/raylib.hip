@@ -16,6 +16,7 @@
 #include "trace_kernels.hpp"
 #include "trace_wavefront.hpp"
 #include "nif_kernels.hpp"
+#include "scene_blob.hpp"
 
 using namespace mi;
 
@@ -326,6 +327,26 @@ int mi_scene_create(const mi_scene_desc* desc, mi_scene** out) {
   if (rc != MI_OK) { delete S; return rc; }
   *out = S;
   return MI_OK;
+}
+
+int mi_scene_create_from_blob(const uint8_t* blob, size_t size, const mi_scene_desc* extras, mi_scene** out) {
+  if (!blob || !extras || !out) { g_err = "mi_scene_create_from_blob: null argument"; return MI_ERR_INVALID_ARG; }
+  *out = nullptr;
+  mi_scene_desc d = *extras;                 // spheres/discs, rng seed, crop window, pathTrace, device
+  std::vector<uint64_t> aligned;             // only used when the caller's bytes are not 16-byte aligned
+  const int rc = guarded([&] {
+    if ((uintptr_t)blob % 16) {
+      aligned.resize((size + 23) / 8);
+      uint8_t* a = (uint8_t*)aligned.data();
+      a += (16 - (uintptr_t)a % 16) % 16;
+      std::memcpy(a, blob, size);
+      blob = a;
+    }
+    try { mi::blob::deserialiseScene(blob, size, d, 16); }          // views into the bytes; create copies them
+    catch (const std::runtime_error& e) { throw ArgError(std::string("mi_scene_create_from_blob: ") + e.what()); }
+  });
+  if (rc != MI_OK) return rc;
+  return mi_scene_create(&d, out);
 }
 
 void mi_scene_destroy(mi_scene* scene) { delete scene; }

@@ -496,3 +496,26 @@ def test_loadNifModel_keras_h5_against_oracle(scenes):
     err = np.abs(got - want) / (np.abs(want) + 1e-3 / 0.02)
     assert np.quantile(err, 0.999) < 0.02 and err.max() < 0.10, (np.quantile(err, 0.999), err.max())
     dev.close()
+
+
+def test_scene_from_serialised_blob_renders_identically(scenes):
+    """mi_scene_create_from_blob (the reference's Serialiser<16> byte stream, src/IpuScene.cpp:51-53) ≡
+    mi_scene_create from arrays: same TraceResult bytes; also from a deliberately misaligned copy, and a
+    truncated blob is refused."""
+    s = scenes["box"]; d = s.desc
+    d.set_image(96, 80); d.samples_per_pixel = 5; d.path_trace = 1
+    want = s.init_ray_stream()
+    ref_dev = irl.IpuScene(d); ref_dev.run(want, irl.MODE_PATH_TRACE); ref_dev.close()
+
+    blob = irl.serialise_scene(d)
+    extras = irl.SceneDesc()
+    extras.rng_seed = d.rng_seed; extras.path_trace = 1
+    extras.spheres, extras.num_spheres, extras.discs, extras.num_discs = d.spheres, d.num_spheres, d.discs, d.num_discs   # not in the blob
+    extras.window_w, extras.window_h, extras.window_c, extras.window_r = d.window_w, d.window_h, d.window_c, d.window_r
+    for view in (blob, irl.aligned_bytes(blob.size + 1)[1:]):
+        view[:] = blob
+        dev = irl.IpuScene.from_blob(view, extras)
+        got = s.init_ray_stream(); dev.run(got, irl.MODE_PATH_TRACE); dev.close()
+        assert got.tobytes() == want.tobytes()
+    with pytest.raises(irl.RaylibError, match="end of byte stream"):
+        irl.IpuScene.from_blob(blob[: blob.size // 2].copy(), extras)
