@@ -129,7 +129,7 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
       need(d.mesh_tris[3 * (size_t)mi_.first_index + t] < mi_.num_vertices, "triangle vertex index out of range");
   }
 
-  // Node array: same bytes, interior link := skip index (preorder subtree end). Also checks that the
+  // Node array: box widened to six floats, interior link := skip index (preorder subtree end). Also checks that the
   // array really is a preorder BVH2 (first child adjacent, second child after it, every node reached).
   const uint32_t N = d.num_nodes;
   std::vector<GNode> nodes(N);
@@ -153,7 +153,10 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
     const mi_bvh_node& n = d.bvh_nodes[i];
     GNode g;
     g.minx = n.min_x; g.miny = n.min_y; g.minz = n.min_z;
-    g.hx = n.dx; g.hy = n.dy; g.hz = n.dz; g.geomID = n.geom_id;
+    g.maxx = n.min_x + half_bits_to_float(n.dx);                  // CompactBVH2Node.cpp:8-10, one rounded add each
+    g.maxy = n.min_y + half_bits_to_float(n.dy);
+    g.maxz = n.min_z + half_bits_to_float(n.dz);
+    g.geomID = n.geom_id;
     if (n.geom_id == MI_INVALID_GEOM) g.link = skip[i];
     else {
       need(n.geom_id < d.num_geometry, "leaf geomID out of range");
@@ -229,6 +232,7 @@ void ensureScratch(mi_scene& S, size_t n) {
 bool g_fullStats = false;
 WaveTune g_tune = {5, 8, 12, 32, 2, 16};
 int g_kernelChoice = 1;           // 0 = nested-loop kernel, 1 = wavefront (global nodes), 2 = wavefront + LDS-staged nodes
+int g_wavesPerSimd = 5;          // MI_RAYLIB_WAVES=4: the 108-VGPR build of the default kernel (4 waves per SIMD)
 
 constexpr uint32_t kLdsBudgetBytes = 160 * 1024 - 1024;     // 160 KiB per CU minus the static allocations
 
@@ -254,6 +258,10 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
     const size_t ldsBytes = (size_t)kParkBytesPerWave * (256 / 64);
     const uint32_t blocks = std::min<uint32_t>((cnt + 511) / 512, 256 * 4);
     hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, true>), dim3(blocks), dim3(256), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW);
+  } else if (!STATS && g_wavesPerSimd == 5) {
+    // 96-VGPR build: 5 waves per SIMD (+4.6 % on the box scene; 6 waves = 80 VGPRs spills in the hot loop: -9 %)
+    const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, false, 5>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW);
   } else {
     const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, 256 * 8);
     hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, false>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW);
@@ -322,6 +330,7 @@ int mi_scene_create(const mi_scene_desc* desc, mi_scene** out) {
     S->params.spheres = nullptr; S->params.discs = nullptr;
     if (const char* e = getenv("MI_RAYLIB_FULL_STATS")) g_fullStats = (e[0] == '1');
     if (const char* e = getenv("MI_RAYLIB_TUNE")) { unsigned a, b, c, dd = 32, k8 = 2, ta = 16; if (sscanf(e, "%u,%u,%u,%u,%u,%u", &a, &b, &c, &dd, &k8, &ta) >= 3) g_tune = {a, b, c, dd, k8, ta}; }
+    if (const char* e = getenv("MI_RAYLIB_WAVES")) g_wavesPerSimd = (e[0] == '4') ? 4 : 5;
     if (const char* e = getenv("MI_RAYLIB_KERNEL")) g_kernelChoice = (e[0] == '0') ? 0 : (e[0] == '2') ? 2 : (e[0] == '3') ? 3 : 1;
   });
   if (rc != MI_OK) { delete S; return rc; }

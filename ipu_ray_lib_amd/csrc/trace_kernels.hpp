@@ -20,13 +20,17 @@
 namespace mi {
 
 // ---- device scene ---------------------------------------------------------------------------------
-struct __attribute__((aligned(8))) GNode {       // 24 B, same bytes as CompactBVH2Node except `link`
-  float minx, miny, minz;
+// 32 B device node = two aligned 16-byte loads. The box is stored as the six floats the reference's box
+// test derives from a CompactBVH2Node on every visit: min and max = min + (float)extent
+// (CompactBVH2Node.cpp:8-10; the binary16 -> binary32 conversion is exact and the add is one rounded
+// binary32 operation, so doing it once at upload gives the same bits). Interleaved (min,max) per axis so
+// a 64-bit register pair feeds the packed subtract/multiply directly.
+struct __attribute__((aligned(16))) GNode {
+  float minx, maxx, miny, maxy, minz, maxz;
   uint32_t link;                                  // interior: skip index; leaf: index into leaves[]
-  uint16_t hx, hy, hz;                            // binary16 extents
-  uint16_t geomID;                                // 0xFFFF = interior
+  uint32_t geomID;                                // 0xFFFF = interior
 };
-static_assert(sizeof(GNode) == 24, "GNode must stay 24 bytes");
+static_assert(sizeof(GNode) == 32, "GNode must stay 32 bytes");
 
 enum : uint32_t { LEAF_TRI = 0, LEAF_SPHERE = 1, LEAF_DISC = 2 };
 
@@ -173,24 +177,21 @@ __device__ __forceinline__ bool traverse(const DeviceScene& sc, f3 o, f3 d, floa
     if (STATS) cs.nodes++;
     float t0 = tMin, t1 = hit.t;
     {
-      const float maxx = nd.minx + half_bits_to_float(nd.hx);
-      float tmin = (nd.minx - o.x) * inv.x, tmax = (maxx - o.x) * inv.x;
+      float tmin = (nd.minx - o.x) * inv.x, tmax = (nd.maxx - o.x) * inv.x;
       if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; }
       tmax *= kSlabScale;
       t0 = tmin > t0 ? tmin : t0;
       t1 = tmax < t1 ? tmax : t1;
     }
     {
-      const float maxy = nd.miny + half_bits_to_float(nd.hy);
-      float tmin = (nd.miny - o.y) * inv.y, tmax = (maxy - o.y) * inv.y;
+      float tmin = (nd.miny - o.y) * inv.y, tmax = (nd.maxy - o.y) * inv.y;
       if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; }
       tmax *= kSlabScale;
       t0 = tmin > t0 ? tmin : t0;
       t1 = tmax < t1 ? tmax : t1;
     }
     {
-      const float maxz = nd.minz + half_bits_to_float(nd.hz);
-      float tmin = (nd.minz - o.z) * inv.z, tmax = (maxz - o.z) * inv.z;
+      float tmin = (nd.minz - o.z) * inv.z, tmax = (nd.maxz - o.z) * inv.z;
       if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; }
       tmax *= kSlabScale;
       t0 = tmin > t0 ? tmin : t0;

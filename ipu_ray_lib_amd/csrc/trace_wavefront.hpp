@@ -39,18 +39,18 @@ enum : uint32_t { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_GEN = 3, PH_FETCH =
 //   keep8    ... or earlier, once fewer than keep8/8 of the lanes that started the burst still traverse
 struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, tradeAt; };
 
-template <bool STATS, bool LDS_NODES, int BLOCK, bool TWO_RAYS>
-__global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : 1) path_trace_wavefront_kernel(DeviceScene sc, mi_trace_result* rays, uint32_t n,
+template <bool STATS, bool LDS_NODES, int BLOCK, bool TWO_RAYS, int WAVES_PER_SIMD = 4>
+__global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK == 256 && WAVES_PER_SIMD > 4) ? WAVES_PER_SIMD : 1) path_trace_wavefront_kernel(DeviceScene sc, mi_trace_result* rays, uint32_t n,
                                                                    uint32_t* workCounter, uint32_t ldsNodeCount, WaveTune tune, uint32_t tileStreamW) {
   __shared__ float sinTbl[92];
   extern __shared__ __attribute__((aligned(16))) unsigned char dynLds[];
   load_sin_table(sinTbl);
   const GNode* ldsNodes = reinterpret_cast<const GNode*>(dynLds);
   if (LDS_NODES) {
-    // stage the first ldsNodeCount nodes (preorder prefix) once per workgroup, 8 B per lane per step
-    const uint2* src = reinterpret_cast<const uint2*>(sc.nodes);
-    uint2* dst = reinterpret_cast<uint2*>(dynLds);
-    for (uint32_t k = threadIdx.x; k < ldsNodeCount * 3; k += blockDim.x) dst[k] = src[k];
+    // stage the first ldsNodeCount nodes (preorder prefix) once per workgroup, 16 B per lane per step
+    const uint4* src = reinterpret_cast<const uint4*>(sc.nodes);
+    uint4* dst = reinterpret_cast<uint4*>(dynLds);
+    for (uint32_t k = threadIdx.x; k < ldsNodeCount * 2; k += blockDim.x) dst[k] = src[k];
     __syncthreads();
   }
 
@@ -209,6 +209,9 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : 1) pat
       const unsigned long long tq0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
       const uint32_t startT = cN + cL;
       uint32_t steps = 0;
+      // lanes only change rays in SHADE/GEN (or in a trade), so "some lane needs the literal box test" is a
+      // per-burst fact
+      bool anyExact = __ballot(exactSlab) != 0ull;
       for (;;) {
         const uint32_t stay = cN;
         if (cN * 4u >= cL * tune.leafAt && cN > 0) {
@@ -226,15 +229,14 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : 1) pat
             // sign of a zero never reaches the result (only t0 > t1 is used). Lanes whose ray has a zero /
             // denormal direction component or a non-finite origin (exactSlab) redo the test with the
             // reference's literal compare/select sequence below, so NaN cases stay bit-identical too.
-            const float maxx = nd.minx + half_bits_to_float(nd.hx);
-            const float maxy = nd.miny + half_bits_to_float(nd.hy);
-            const float maxz = nd.minz + half_bits_to_float(nd.hz);
-            const float ax = (nd.minx - o.x) * inv.x, bx = (maxx - o.x) * inv.x;
-            const float ay = (nd.miny - o.y) * inv.y, by = (maxy - o.y) * inv.y;
-            const float az = (nd.minz - o.z) * inv.z, bz = (maxz - o.z) * inv.z;
+            // The far side is scaled ONCE: x -> fl(x * kSlabScale) is monotone non-decreasing, so
+            // min(fl(bx*s), fl(by*s), fl(bz*s)) == fl(min(bx, by, bz) * s) bit for bit (no NaNs on this path).
+            const float ax = (nd.minx - o.x) * inv.x, bx = (nd.maxx - o.x) * inv.x;
+            const float ay = (nd.miny - o.y) * inv.y, by = (nd.maxy - o.y) * inv.y;
+            const float az = (nd.minz - o.z) * inv.z, bz = (nd.maxz - o.z) * inv.z;
             float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
-            float t1 = fminf(fminf(fmaxf(ax, bx) * kSlabScale, fmaxf(ay, by) * kSlabScale), fminf(fmaxf(az, bz) * kSlabScale, hit.t));
-            if (__ballot(exactSlab)) {
+            float t1 = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * kSlabScale, hit.t);
+            if (TWO_RAYS ? (__ballot(exactSlab) != 0ull) : anyExact) {
               if (exactSlab) {
                 t0 = 0.f; t1 = hit.t;
                 { float tmin = ax, tmax = bx; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
