@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -37,8 +38,13 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 
-constexpr uint32_t kNifRows = 128;       // rays per workgroup pass (8 waves: 4 output-feature groups x 2 row halves)
-constexpr uint32_t kNifThreads = 512;
+// Two workgroup shapes of the same kernel (template parameters MT = 16-ray tiles per wave, RG = row groups):
+//   wide  : 4 waves x (TILES x 12) tiles, 192 rays per pass, one wave per SIMD with the accumulators in AGPRs.
+//           Every packed weight fragment is fetched ONCE per workgroup and amortised over 12 MFMAs, which
+//           takes the L1/TA weight stream (the limiter of the tall shape, profiles/r01_nif_pmc.csv) down 3x.
+//           Needs 192 x stride x 2 B of LDS: fits for hidden widths <= 320 with 48 features.
+//   tall  : 8 waves = 4 output-feature groups x 2 row halves, 128 rays per pass (any width up to 384).
+constexpr uint32_t kNifMaxLdsBytes = 160 * 1024 - 512;
 constexpr uint32_t kNifMaxLayers = 16;
 constexpr uint32_t kNifMaxTilesPerWave = 6;   // output-feature tiles (of 16) per wave: supports widths up to 384
 
@@ -196,30 +202,165 @@ __global__ void __launch_bounds__(256) escaped_uv_kernel(const mi_trace_result* 
   if (escaped) index[base + __popcll(mask & ((1ull << lane) - 1ull))] = i;
 }
 
+// One dense layer for one wave: TN output-feature tiles (nt = ng + 4a) x MT ray tiles, fully unrolled, with its
+// own accumulators (so the register allocator never has to shuffle one layer shape's accumulators around
+// another's code), the next k-step's weight fragments in flight while the current ones feed the matrix cores,
+// and the bias / ReLU / binary16 store (or the decode + environment add for the last layer) as epilogue.
+template <uint32_t TN, uint32_t MT>
+__device__ __forceinline__ void nif_dense_layer(const NifParams& P, const NifLayerDesc& L, bool last, _Float16* X, uint32_t stride,
+                                                uint32_t rowBase, uint32_t ng, uint32_t lane, const h8* __restrict__ weights,
+                                                const float* __restrict__ bias, uint32_t row0, uint32_t total,
+                                                const uint32_t* __restrict__ idx, float* __restrict__ bgrOut, mi_trace_result* rays) {
+  f4v acc[TN][MT];
+  // The accumulators start from the bias: it is the C operand of the first k-step's MFMAs (no zero fill, no bias add).
+  f4v bv[TN];
+#pragma unroll
+  for (uint32_t a = 0; a < TN; ++a) {
+    bv[a] = (f4v){0.f, 0.f, 0.f, 0.f};
+    if (L.bOffset != 0xFFFFFFFFu) bv[a] = *reinterpret_cast<const f4v*>(&bias[L.bOffset + 16 * (ng + 4 * a) + 4 * (lane >> 4)]);
+  }
+  // Weight stream: three named fragment sets (k-steps 3j, 3j+1, 3j+2), each loaded two k-steps before it is used.
+  // hipcc sinks ordinary loads down to their first use here (it minimises live ranges at this register
+  // pressure: the .s showed "load, s_waitcnt vmcnt(0), mfma" every k-step), so the loads are inline asm, invisible
+  // to its scheduler, and their completion is counted by hand (cdna_hip_programming.md §5.7 form ii): loads return
+  // in order, every step issues exactly TN of them, so "all but the newest 2*TN have landed" is the set about to be
+  // used. Every destination is named "+v" in the wait, which keeps the consumers below it.
+  h8 wA[TN], wB[TN], wC[TN];
+  const uint32_t kSteps = L.kSteps, kLast = kSteps - 1;
+  // Fragment (nt, ks) is 1 KiB at weights + wOffset + (nt*kSteps + ks)*64 (+ lane): a wave-uniform base, so the
+  // loads use the SGPR-base + VGPR-offset form and need ONE address VGPR (lane*16) for all of them.
+  const uint32_t laneOff = lane * 16u;
+  const uint32_t ngU = (uint32_t)__builtin_amdgcn_readfirstlane((int)ng);
+  auto loadW = [&](h8 (&w)[TN], uint32_t ks) {
+    ks = ks < kLast ? ks : kLast;                          // past the end: re-read the last fragment (keeps the count uniform)
+#pragma unroll
+    for (uint32_t a = 0; a < TN; ++a) {
+      // all-scalar arithmetic (kernel arguments + ngU): the base is produced by SALU instructions, which a VMEM
+      // instruction may read without wait states (a v_readfirstlane result would need 5: §5.7 item 2)
+      // (32-bit offset arithmetic: there is no 64-bit scalar multiply, a 64-bit product would go through VALU registers;
+      // and the offset is pinned scalar with readfirstlane; the 64-bit add that consumes it is SALU)
+      const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)((((ngU + 4 * a) * kSteps) + ks) << 10));
+      const uint64_t sbase = (uint64_t)(uintptr_t)(weights + L.wOffset) + off;
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(w[a]) : "v"(laneOff), "s"(sbase));
+    }
+  };
+  auto landed = [&](h8 (&w)[TN], auto outstanding) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(outstanding)::value));
+#pragma unroll
+    for (uint32_t a = 0; a < TN; ++a) asm volatile("" : "+v"(w[a]));
+  };
+  // Activation fragments come from LDS through inline-asm reads as well, two in flight: hipcc otherwise emits
+  // "ds_read; s_waitcnt lgkmcnt(0); TN mfma" per ray tile, exposing the LDS latency MT times per k-step with only two
+  // waves per SIMD to cover it. Same hand-counted scheme: reads return in order, lgkmcnt(1) = all but the newest.
+  const uint32_t xAddr0 = (uint32_t)(uintptr_t)X + ((rowBase + (lane & 15)) * stride + L.inBase + 8 * (lane >> 4)) * 2u;
+  const uint32_t mStep = 16u * stride * 2u;
+  auto readX = [&](h8& x, uint32_t addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(x) : "v"(addr)); };
+  auto step = [&](const h8 (&w)[TN], uint32_t ks, auto first) {
+    // B fragment: X^T[k][ray] = X[ray = rowBase + 16m + (lane&15)][k = 32ks + 8(lane>>4) + j]
+    const uint32_t a0 = xAddr0 + 64u * ks;
+    h8 xb[2];
+    readX(xb[0], a0);
+#pragma unroll
+    for (uint32_t m = 0; m < MT; ++m) {
+      if (m + 1 < MT) {
+        readX(xb[(m + 1) & 1], a0 + (m + 1) * mStep);
+        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(xb[m & 1]));
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xb[m & 1]));
+      }
+#pragma unroll
+      for (uint32_t a = 0; a < TN; ++a)
+        acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[a], xb[m & 1], decltype(first)::value ? bv[a] : acc[a][m], 0, 0, 0);
+    }
+  };
+  using TwoSets = std::integral_constant<int, 2 * TN>;
+  loadW(wA, 0);
+  loadW(wB, 1);
+  loadW(wC, 2); landed(wA, TwoSets{}); step(wA, 0, std::true_type{});
+  loadW(wA, 3); landed(wB, TwoSets{}); if (1 < kSteps) step(wB, 1, std::false_type{});
+  loadW(wB, 4); landed(wC, TwoSets{}); if (2 < kSteps) step(wC, 2, std::false_type{});
+  for (uint32_t ks = 3; ks < kSteps; ks += 3) {
+    loadW(wC, ks + 2); landed(wA, TwoSets{}); step(wA, ks, std::false_type{});
+    loadW(wA, ks + 3); landed(wB, TwoSets{}); if (ks + 1 < kSteps) step(wB, ks + 1, std::false_type{});
+    loadW(wB, ks + 4); landed(wC, TwoSets{}); if (ks + 2 < kSteps) step(wC, ks + 2, std::false_type{});
+  }
+  // drain: the two sets still in flight own their registers until they land
+  asm volatile("s_waitcnt vmcnt(0)");
+#pragma unroll
+  for (uint32_t a = 0; a < TN; ++a) { asm volatile("" : "+v"(wA[a])); asm volatile("" : "+v"(wB[a])); asm volatile("" : "+v"(wC[a])); }
+  __syncthreads();   // every wave has read its inputs: X[.., 0..N) may be overwritten
+#pragma unroll
+  for (uint32_t a = 0; a < TN; ++a) {
+    const uint32_t nt = ng + 4 * a;
+    if (16 * nt < L.n) {
+      // D fragment: rows (= output features) 16nt + 4(lane>>4) + reg, column (= ray) 16m + (lane&15)
+      const uint32_t f0 = 16 * nt + 4 * (lane >> 4);
+#pragma unroll
+      for (uint32_t m = 0; m < MT; ++m) {
+        f4v y = acc[a][m];
+        const uint32_t r = rowBase + 16 * m + (lane & 15);
+        if (!last) {
+          // ReLU on the rounded halves (two packed max): rounding is monotone and keeps the sign, so
+          // max(round(y), 0) == round(max(y, 0))
+          h4 yh = {(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
+          if (L.relu) yh = __builtin_elementwise_max(yh, (h4){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f});
+          *reinterpret_cast<h4*>(&X[r * stride + f0]) = yh;
+        } else if (nt == 0 && (lane >> 4) == 0 && row0 + r < total) {
+          // decode (NifModel.cpp:222-246): y*max + mean, exp for log-tonemapped models
+          if (L.relu) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) y[q] = y[q] > 0.f ? y[q] : 0.f;
+          }
+          float o[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            o[c] = y[c] * P.maxValue + P.mean[c];
+            if (P.logTonemap) o[c] = expf(o[c]);
+          }
+          const uint32_t row = row0 + r;
+          if (bgrOut) { bgrOut[3 * row] = o[0]; bgrOut[3 * row + 1] = o[1]; bgrOut[3 * row + 2] = o[2]; }
+          if (rays) {
+            mi_trace_result* res = rays + (idx ? idx[row] : row);
+            const mi_vec3 tp = res->h.throughput;
+            res->rgb.x += tp.x * o[2];          // BGR -> RGB (codelets/TraceCodelets.cpp:376)
+            res->rgb.y += tp.y * o[1];
+            res->rgb.z += tp.z * o[0];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // The MLP. rows: `numRows` (or *countPtr when countPtr != nullptr) entries; entry r reads
 // u[idx ? idx[r] : r], v[...]; result goes to bgrOut[3*r..] (stand-alone) and/or is added to
 // rays[idx[r]].rgb as throughput * (b,g,r)->(r,g,b) (PostProcessEscapedRays).
-template <uint32_t TILES>
-__global__ void __launch_bounds__(kNifThreads) nif_mlp_kernel(NifParams P, const h8* __restrict__ weights, const float* __restrict__ bias,
+// TILES = most output-feature tiles any layer gives a wave; layers with fewer run their own instantiation.
+template <uint32_t TILES, uint32_t MT, uint32_t RG>
+__global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : 1) nif_mlp_kernel(NifParams P, const h8* __restrict__ weights, const float* __restrict__ bias,
                                                       const float* __restrict__ u, const float* __restrict__ v,
                                                       const uint32_t* __restrict__ idx, const uint32_t* __restrict__ countPtr,
                                                       uint32_t numRows, float* __restrict__ bgrOut, mi_trace_result* rays) {
+  constexpr uint32_t kNifRows = 16u * MT * RG;                    // rays per workgroup pass
   extern __shared__ __attribute__((aligned(16))) _Float16 X[];   // [kNifRows][P.stride]
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t ng = wave & 3u, rowBase = 64u * (wave >> 2);    // output-feature group, row half
+  const uint32_t ng = wave & 3u, rowBase = 16u * MT * (wave >> 2);   // output-feature group, row group
   const uint32_t total = countPtr ? *countPtr : numRows;
   const uint32_t stride = P.stride;
   const uint32_t E = P.embedDim, F = 4 * E;
 
   for (uint32_t row0 = blockIdx.x * kNifRows; row0 < total; row0 += gridDim.x * kNifRows) {
     __syncthreads();   // previous pass finished with X
-    // zero the K-padding columns behind the features, then write the Fourier features
-    for (uint32_t e = tid; e < kNifRows * (stride - P.featBase - F); e += blockDim.x) {
-      const uint32_t r = e / (stride - P.featBase - F), c = e % (stride - P.featBase - F);
+    // zero the K-padding columns behind the features, then write the Fourier features. Items are numbered
+    // column-major (e = column * kNifRows + row) so the row/column split divides by a compile-time constant.
+    const uint32_t padCols = stride - P.featBase - F;
+    for (uint32_t e = tid; e < kNifRows * padCols; e += blockDim.x) {
+      const uint32_t r = e % kNifRows, c = e / kNifRows;
       X[r * stride + P.featBase + F + c] = (_Float16)0.f;
     }
     for (uint32_t e = tid; e < kNifRows * E * 2; e += blockDim.x) {
-      const uint32_t r = e / (2 * E), q = e % (2 * E), j = q % E, isV = q / E;
+      const uint32_t r = e % kNifRows, q = e / kNifRows, isV = q >= E ? 1u : 0u, j = q - isV * E;
       const uint32_t row = row0 + r;
       float coord = 0.f;
       if (row < total) { const uint32_t src = idx ? idx[row] : row; coord = isV ? v[src] : u[src]; }
@@ -229,103 +370,23 @@ __global__ void __launch_bounds__(kNifThreads) nif_mlp_kernel(NifParams P, const
       sincos_half_phase(phase, fs, fc);
       const _Float16 sn = (_Float16)fs, cs = (_Float16)fc;
       // feature order [sin u | sin v | cos u | cos v] (NifModel.cpp:216)
-      X[r * stride + P.featBase + isV * E + j] = sn;
-      X[r * stride + P.featBase + 2 * E + isV * E + j] = cs;
+      X[r * stride + P.featBase + q] = sn;
+      X[r * stride + P.featBase + 2 * E + q] = cs;
     }
     __syncthreads();
 
     for (uint32_t l = 0; l < P.numLayers; ++l) {
       const NifLayerDesc L = P.layers[l];
-      f4v acc[TILES][4];
-#pragma unroll
-      for (uint32_t a = 0; a < TILES; ++a)
-#pragma unroll
-        for (uint32_t m = 0; m < 4; ++m) acc[a][m] = (f4v){0.f, 0.f, 0.f, 0.f};
-      const uint32_t tilesLayer = L.nTiles >> 2;            // tiles per wave in this layer (wave-uniform)
-      const h8* wbase = weights + L.wOffset + lane;
-      if (tilesLayer == TILES) {
-        // Fast path (the hidden layers): fully unrolled over this wave's TILES tiles; the next k-step's
-        // weight fragments are in flight while the current ones feed the matrix cores.
-        h8 wc[TILES], wn[TILES];
-#pragma unroll
-        for (uint32_t a = 0; a < TILES; ++a) wc[a] = wbase[((size_t)(ng + 4 * a) * L.kSteps) * 64];
-        for (uint32_t ks = 0; ks < L.kSteps; ++ks) {
-          const uint32_t kn = (ks + 1 < L.kSteps) ? ks + 1 : ks;
-#pragma unroll
-          for (uint32_t a = 0; a < TILES; ++a) wn[a] = wbase[((size_t)(ng + 4 * a) * L.kSteps + kn) * 64];
-          h8 xb[4];
-#pragma unroll
-          for (uint32_t m = 0; m < 4; ++m)   // B fragment: X^T[k][ray] = X[ray = rowBase + 16m + (lane&15)][k = 32ks + 8(lane>>4) + j]
-            xb[m] = *reinterpret_cast<const h8*>(&X[(rowBase + 16 * m + (lane & 15)) * stride + L.inBase + 32 * ks + 8 * (lane >> 4)]);
-#pragma unroll
-          for (uint32_t a = 0; a < TILES; ++a)
-#pragma unroll
-            for (uint32_t m = 0; m < 4; ++m) acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[a], xb[m], acc[a][m], 0, 0, 0);
-#pragma unroll
-          for (uint32_t a = 0; a < TILES; ++a) wc[a] = wn[a];
-        }
-      } else {
-        // Generic path (e.g. the 3-wide output layer): one tile at a time, rolled.
-        for (uint32_t ks = 0; ks < L.kSteps; ++ks) {
-          h8 xb[4];
-#pragma unroll
-          for (uint32_t m = 0; m < 4; ++m)
-            xb[m] = *reinterpret_cast<const h8*>(&X[(rowBase + 16 * m + (lane & 15)) * stride + L.inBase + 32 * ks + 8 * (lane >> 4)]);
-#pragma unroll
-          for (uint32_t a = 0; a < TILES; ++a) {
-            if (a < tilesLayer) {
-              const h8 w = wbase[((size_t)(ng + 4 * a) * L.kSteps + ks) * 64];
-#pragma unroll
-              for (uint32_t m = 0; m < 4; ++m) acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, xb[m], acc[a][m], 0, 0, 0);
-            }
-          }
-        }
-      }
-      __syncthreads();   // every wave has read its inputs: X[.., 0..N) may be overwritten
       const bool last = (l + 1 == P.numLayers);
-#pragma unroll
-      for (uint32_t a = 0; a < TILES; ++a) {
-        const uint32_t nt = ng + 4 * a;
-        if (a < tilesLayer && 16 * nt < L.n) {
-          // D fragment: rows (= output features) 16nt + 4(lane>>4) + reg, column (= ray) 16m + (lane&15)
-          const uint32_t f0 = 16 * nt + 4 * (lane >> 4);
-#pragma unroll
-          for (uint32_t m = 0; m < 4; ++m) {
-            f4v y = acc[a][m];
-            if (L.bOffset != 0xFFFFFFFFu) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) y[q] += bias[L.bOffset + f0 + q];
-            }
-            if (L.relu) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) y[q] = y[q] > 0.f ? y[q] : 0.f;
-            }
-            const uint32_t r = rowBase + 16 * m + (lane & 15);
-            if (!last) {
-              h4 yh = {(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
-              *reinterpret_cast<h4*>(&X[r * stride + f0]) = yh;
-            } else if (nt == 0 && (lane >> 4) == 0 && row0 + r < total) {
-              // decode (NifModel.cpp:222-246): y*max + mean, exp for log-tonemapped models
-              float o[3];
-#pragma unroll
-              for (int c = 0; c < 3; ++c) {
-                o[c] = y[c] * P.maxValue + P.mean[c];
-                if (P.logTonemap) o[c] = expf(o[c]);
-              }
-              const uint32_t row = row0 + r;
-              if (bgrOut) { bgrOut[3 * row] = o[0]; bgrOut[3 * row + 1] = o[1]; bgrOut[3 * row + 2] = o[2]; }
-              if (rays) {
-                mi_trace_result* res = rays + (idx ? idx[row] : row);
-                const mi_vec3 tp = res->h.throughput;
-                res->rgb.x += tp.x * o[2];          // BGR -> RGB (codelets/TraceCodelets.cpp:376)
-                res->rgb.y += tp.y * o[1];
-                res->rgb.z += tp.z * o[0];
-              }
-            }
-          }
-        }
-      }
-      __syncthreads();
+      const uint32_t tilesLayer = L.nTiles >> 2;            // tiles per wave in this layer (wave-uniform)
+#define MI_NIF_LAYER(TN) nif_dense_layer<TN, MT>(P, L, last, X, stride, rowBase, ng, lane, weights, bias, row0, total, idx, bgrOut, rays)
+      if (tilesLayer == TILES) MI_NIF_LAYER(TILES);
+      else if (TILES > 1 && tilesLayer == 1) MI_NIF_LAYER(1);
+      else if (TILES > 2 && tilesLayer == 2) MI_NIF_LAYER(2);
+      else if (TILES > 3 && tilesLayer == 3) MI_NIF_LAYER(3);
+      else if (TILES > 4 && tilesLayer == 4) MI_NIF_LAYER(4);
+      else if (TILES > 5 && tilesLayer == 5) MI_NIF_LAYER(5);
+#undef MI_NIF_LAYER
     }
   }
 }
@@ -333,18 +394,39 @@ __global__ void __launch_bounds__(kNifThreads) nif_mlp_kernel(NifParams P, const
 inline void nif_launch_mlp(const NifDevice& nif, const float* u, const float* v, const uint32_t* idx, const uint32_t* countPtr,
                            uint32_t numRows, float* bgrOut, mi_trace_result* rays, hipStream_t stream) {
   if (numRows == 0) return;
-  const size_t lds = (size_t)kNifRows * nif.p.stride * sizeof(_Float16);
-  uint32_t blocks = (numRows + kNifRows - 1) / kNifRows;
-  if (blocks > 256 * 8) blocks = 256 * 8;          // grid-stride beyond 8 row-blocks per CU
   uint32_t maxTiles = 1;
   for (uint32_t l = 0; l < nif.p.numLayers; ++l) maxTiles = std::max(maxTiles, nif.p.layers[l].nTiles / 4);
-  auto launch = [&](auto kern) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kNifThreads), lds, stream, nif.p, nif.d_weights, nif.d_bias, u, v, idx, countPtr, numRows, bgrOut, rays);
+  // shape: MT ray tiles per wave x RG row groups (see the table at the top); MI_RAYLIB_NIF_SHAPE=t4|t6|w6|w8|w12 overrides
+  static const char* shapeEnv = getenv("MI_RAYLIB_NIF_SHAPE");
+  uint32_t mt = 6, rg = 2;
+  if (shapeEnv) { rg = shapeEnv[0] == 't' ? 2 : 1; mt = (uint32_t)atoi(shapeEnv + 1); }
+  if (!(rg == 2 && (mt == 4 || mt == 6)) && !(rg == 1 && (mt == 6 || mt == 8 || mt == 12))) { mt = 6; rg = 2; }
+  if (!(mt == 4 && rg == 2) && ((size_t)16 * mt * rg * nif.p.stride * sizeof(_Float16) > kNifMaxLdsBytes || maxTiles > 5)) { mt = 4; rg = 2; }
+  auto launch = [&](auto kern, uint32_t rowsPerPass, uint32_t threads) {
+    const size_t lds = (size_t)rowsPerPass * nif.p.stride * sizeof(_Float16);
+    uint32_t blocks = (numRows + rowsPerPass - 1) / rowsPerPass;
+    if (blocks > 256 * 8) blocks = 256 * 8;          // grid-stride beyond 8 passes per CU
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNifMaxLdsBytes);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, nif.p, nif.d_weights, nif.d_bias, u, v, idx, countPtr, numRows, bgrOut, rays);
   };
-  if (maxTiles <= 2) launch(nif_mlp_kernel<2>);
-  else if (maxTiles <= 5) launch(nif_mlp_kernel<5>);
-  else launch(nif_mlp_kernel<6>);
+  if (mt == 6 && rg == 2) {
+    if (maxTiles <= 2) launch(nif_mlp_kernel<2, 6, 2>, 192, 512);
+    else launch(nif_mlp_kernel<5, 6, 2>, 192, 512);
+  } else if (mt == 12) {
+    if (maxTiles <= 2) launch(nif_mlp_kernel<2, 12, 1>, 192, 256);
+    else launch(nif_mlp_kernel<5, 12, 1>, 192, 256);
+  } else if (mt == 8) {
+    if (maxTiles <= 2) launch(nif_mlp_kernel<2, 8, 1>, 128, 256);
+    else launch(nif_mlp_kernel<5, 8, 1>, 128, 256);
+  } else if (mt == 6) {
+    if (maxTiles <= 2) launch(nif_mlp_kernel<2, 6, 1>, 96, 256);
+    else launch(nif_mlp_kernel<5, 6, 1>, 96, 256);
+  } else {
+    if (maxTiles <= 2) launch(nif_mlp_kernel<2, 4, 2>, 128, 512);
+    else if (maxTiles <= 4) launch(nif_mlp_kernel<4, 4, 2>, 128, 512);
+    else if (maxTiles <= 5) launch(nif_mlp_kernel<5, 4, 2>, 128, 512);
+    else launch(nif_mlp_kernel<6, 4, 2>, 128, 512);
+  }
 }
 
 // mi_nif_infer_device: every row is evaluated (no compaction)
