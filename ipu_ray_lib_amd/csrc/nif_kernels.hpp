@@ -11,14 +11,16 @@
 // to binary16; weights and inter-layer activations are binary16; products accumulate in binary32
 // on v_mfma_f32_16x16x32_f16 (the IPU accumulates in half: ours is the more accurate of the two).
 //
-// Kernel shape: one 512-thread workgroup owns 128 rays; wave w evaluates output-feature
-// tiles {w&3, (w&3)+4, ...} for the 64 rays of row half w>>2, so each packed weight fragment is fetched
-// by two waves (second one hits L1) and amortised over 4 MFMAs; the next k-step's fragments are
-// prefetched into a second register set while the current ones feed the matrix cores. Activations live in LDS as
-// [64][stride] binary16; the dense layers are evaluated transposed, Y^T = W^T · X^T, so that the
-// MFMA result fragment of a lane is 4 consecutive output features of ONE ray and goes back to LDS
-// as one 8-byte store. W^T is pre-packed on the host in exact A-fragment order, so every weight
-// load is a fully coalesced 1 KiB wave read served from L2.
+// Kernel shape: a 256-thread workgroup owns 96 rays (two workgroups per CU); wave w evaluates
+// output-feature tiles {w, w+4, ...} for all 96 rays, so every packed weight fragment is fetched once per
+// workgroup and feeds 6 MFMAs. Activations live in LDS as [rays][stride] binary16; the dense layers are
+// evaluated transposed, Y^T = W^T · X^T, so that the MFMA result fragment of a lane is 4 consecutive output
+// features of ONE ray and goes back to LDS as one 8-byte store. W^T is pre-packed on the host in exact
+// A-fragment order, so every weight load is a fully coalesced 1 KiB wave read served from L2. Both operand
+// streams are software-pipelined with inline-asm loads whose completion is counted by hand (hipcc sinks its own
+// loads to their first use at this register pressure): weights three k-steps deep in registers, activation
+// fragments two deep. Other shapes (8 waves x 64/96 rays, 4 waves x 64/128/192 rays) are kept selectable
+// (MI_RAYLIB_NIF_SHAPE) for widths whose LDS image does not fit and for the measurements in DESIGN.md.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -99,7 +101,8 @@ struct NifDevice {
     NifParams P{};
     P.numLayers = numLayers; P.embedDim = embedDim; P.featBase = featBase;
     const uint32_t kPadMax = ((featBase + F + 31u) & ~31u);
-    P.stride = kPadMax + 16;                      // +16 halves: rows start 8 banks apart -> the ds_read_b128 lane groups
+    P.stride = kPadMax + 16; if (const char* e = getenv("MI_RAYLIB_NIF_PAD")) P.stride = kPadMax + (uint32_t)atoi(e);
+                     // +16 halves: rows start 8 banks apart -> the ds_read_b128 lane groups
                                                   // (rows l&15, k-chunk l>>4) hit 16 disjoint 4-bank slots (measured: +8 gave 2-way conflicts)
     P.maxValue = maxValue; P.mean[0] = mean[0]; P.mean[1] = mean[1]; P.mean[2] = mean[2]; P.logTonemap = logTonemap;
     std::vector<_Float16> packed;
@@ -338,7 +341,7 @@ __device__ __forceinline__ void nif_dense_layer(const NifParams& P, const NifLay
 // rays[idx[r]].rgb as throughput * (b,g,r)->(r,g,b) (PostProcessEscapedRays).
 // TILES = most output-feature tiles any layer gives a wave; layers with fewer run their own instantiation.
 template <uint32_t TILES, uint32_t MT, uint32_t RG>
-__global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : 1) nif_mlp_kernel(NifParams P, const h8* __restrict__ weights, const float* __restrict__ bias,
+__global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : (MT == 4 && RG == 1) ? 3 : 1) nif_mlp_kernel(NifParams P, const h8* __restrict__ weights, const float* __restrict__ bias,
                                                       const float* __restrict__ u, const float* __restrict__ v,
                                                       const uint32_t* __restrict__ idx, const uint32_t* __restrict__ countPtr,
                                                       uint32_t numRows, float* __restrict__ bgrOut, mi_trace_result* rays) {
@@ -396,11 +399,11 @@ inline void nif_launch_mlp(const NifDevice& nif, const float* u, const float* v,
   if (numRows == 0) return;
   uint32_t maxTiles = 1;
   for (uint32_t l = 0; l < nif.p.numLayers; ++l) maxTiles = std::max(maxTiles, nif.p.layers[l].nTiles / 4);
-  // shape: MT ray tiles per wave x RG row groups (see the table at the top); MI_RAYLIB_NIF_SHAPE=t4|t6|w6|w8|w12 overrides
-  static const char* shapeEnv = getenv("MI_RAYLIB_NIF_SHAPE");
-  uint32_t mt = 6, rg = 2;
+  // shape: MT ray tiles per wave x RG row groups (see the table at the top); MI_RAYLIB_NIF_SHAPE=t4|t6|w4|w6|w8|w12 overrides (default w6)
+  const char* shapeEnv = getenv("MI_RAYLIB_NIF_SHAPE");
+  uint32_t mt = 6, rg = 1;
   if (shapeEnv) { rg = shapeEnv[0] == 't' ? 2 : 1; mt = (uint32_t)atoi(shapeEnv + 1); }
-  if (!(rg == 2 && (mt == 4 || mt == 6)) && !(rg == 1 && (mt == 6 || mt == 8 || mt == 12))) { mt = 6; rg = 2; }
+  if (!(rg == 2 && (mt == 4 || mt == 6)) && !(rg == 1 && (mt == 4 || mt == 6 || mt == 8 || mt == 12))) { mt = 6; rg = 1; }
   if (!(mt == 4 && rg == 2) && ((size_t)16 * mt * rg * nif.p.stride * sizeof(_Float16) > kNifMaxLdsBytes || maxTiles > 5)) { mt = 4; rg = 2; }
   auto launch = [&](auto kern, uint32_t rowsPerPass, uint32_t threads) {
     const size_t lds = (size_t)rowsPerPass * nif.p.stride * sizeof(_Float16);
@@ -421,6 +424,9 @@ inline void nif_launch_mlp(const NifDevice& nif, const float* u, const float* v,
   } else if (mt == 6) {
     if (maxTiles <= 2) launch(nif_mlp_kernel<2, 6, 1>, 96, 256);
     else launch(nif_mlp_kernel<5, 6, 1>, 96, 256);
+  } else if (mt == 4 && rg == 1) {
+    if (maxTiles <= 2) launch(nif_mlp_kernel<2, 4, 1>, 64, 256);
+    else launch(nif_mlp_kernel<5, 4, 1>, 64, 256);
   } else {
     if (maxTiles <= 2) launch(nif_mlp_kernel<2, 4, 2>, 128, 512);
     else if (maxTiles <= 4) launch(nif_mlp_kernel<4, 4, 2>, 128, 512);

@@ -390,12 +390,15 @@ def _nif_weights(rng, hidden=320, embed=12, layers=6):
     return ks, bs, relu
 
 
-def test_nif_mlp_against_oracle(scenes):
-    """MFMA MLP vs the oracle's fp16-rounded-inputs / fp32-accumulate restatement. Tolerance: the decoded
+@pytest.mark.parametrize("shape", ["w6", "t4", "t6", "w4", "w8", "w12"])
+def test_nif_mlp_against_oracle(scenes, shape, monkeypatch):
+    """(every workgroup shape of the kernel: w6 is the default, the others are selectable)
+    MFMA MLP vs the oracle's fp16-rounded-inputs / fp32-accumulate restatement. Tolerance: the decoded
     (exp'd) radiance must agree to 2% relative + 1e-3 absolute for 99.9% of samples and 10% for all — fp32
     accumulation ORDER differs (MFMA 32-wide k blocks vs sequential), activations are re-rounded to binary16
     at every layer so a 1-ulp fp32 difference can flip a binary16 rounding, and exp amplifies by |y*max|."""
     import torch
+    monkeypatch.setenv("MI_RAYLIB_NIF_SHAPE", shape)
     rng = np.random.default_rng(5)
     ks, bs, relu = _nif_weights(rng)
     mean = np.array([-2.3514461517333984, -2.2660605907440186, -1.9648972749710083], np.float32) - np.float32(1e-8)
