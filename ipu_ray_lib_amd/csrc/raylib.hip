@@ -258,6 +258,13 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
     const size_t ldsBytes = (size_t)kParkBytesPerWave * (256 / 64);
     const uint32_t blocks = std::min<uint32_t>((cnt + 511) / 512, 256 * 4);
     hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, true>), dim3(blocks), dim3(256), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW);
+  } else if (g_kernelChoice == 4) {
+    // primitive tests pooled across the workgroup (LEAFQ): 17 KiB of LDS per workgroup
+    const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, 256 * 8);
+    if (!STATS && g_wavesPerSimd == 5)
+      hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, false, 5, true>), dim3(blocks), dim3(256), kLeafQBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW);
+    else
+      hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, false, 4, true>), dim3(blocks), dim3(256), kLeafQBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW);
   } else if (!STATS && g_wavesPerSimd == 5) {
     // 96-VGPR build: 5 waves per SIMD (+4.6 % on the box scene; 6 waves = 80 VGPRs spills in the hot loop: -9 %)
     const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, 256 * 8);
@@ -329,9 +336,9 @@ int mi_scene_create(const mi_scene_desc* desc, mi_scene** out) {
     S->params.mesh_normals = nullptr; S->params.mat_ids = nullptr; S->params.materials = nullptr; S->params.bvh_nodes = nullptr;
     S->params.spheres = nullptr; S->params.discs = nullptr;
     if (const char* e = getenv("MI_RAYLIB_FULL_STATS")) g_fullStats = (e[0] == '1');
-    if (const char* e = getenv("MI_RAYLIB_TUNE")) { unsigned a, b, c, dd = 32, k8 = 2, ta = 16; if (sscanf(e, "%u,%u,%u,%u,%u,%u", &a, &b, &c, &dd, &k8, &ta) >= 3) g_tune = {a, b, c, dd, k8, ta}; }
+    if (const char* e = getenv("MI_RAYLIB_TUNE")) { unsigned a, b, c, dd = 32, k8 = 2, ta = 16, qp = 4, qs = 48; if (sscanf(e, "%u,%u,%u,%u,%u,%u,%u,%u", &a, &b, &c, &dd, &k8, &ta, &qp, &qs) >= 3) g_tune = {a, b, c, dd, k8, ta, qp, qs}; }
     if (const char* e = getenv("MI_RAYLIB_WAVES")) g_wavesPerSimd = (e[0] == '4') ? 4 : 5;
-    if (const char* e = getenv("MI_RAYLIB_KERNEL")) g_kernelChoice = (e[0] == '0') ? 0 : (e[0] == '2') ? 2 : (e[0] == '3') ? 3 : 1;
+    if (const char* e = getenv("MI_RAYLIB_KERNEL")) g_kernelChoice = (e[0] == '0') ? 0 : (e[0] == '2') ? 2 : (e[0] == '3') ? 3 : (e[0] == '4') ? 4 : 1;
   });
   if (rc != MI_OK) { delete S; return rc; }
   *out = S;

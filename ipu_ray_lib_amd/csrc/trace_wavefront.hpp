@@ -29,7 +29,24 @@ namespace mi {
 constexpr uint32_t kParkGroups = 9;      // uint4 groups per parked ray
 constexpr uint32_t kParkBytesPerWave = kParkGroups * 64 * 16 + 2 * 64 * 4;   // + phase words + match list
 
-enum : uint32_t { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_GEN = 3, PH_FETCH = 4, PH_DONE = 5 };
+enum : uint32_t { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_GEN = 3, PH_FETCH = 4, PH_DONE = 5, PH_WAIT = 6 };
+
+// LEAFQ variant: primitive tests are pooled across the WORKGROUP. A lane that reaches a leaf
+// writes a request (origin, direction, shear, leaf index: 11 dwords) into its own LDS slot, appends its thread
+// id to a 256-entry ring and waits (PH_WAIT). Whichever wave next finds 64 requests in the ring claims them
+// (compare-and-swap on the ring head) and runs ONE primitive test per lane for them - 64 of 64 lanes busy instead
+// of the ~15 a single wave has waiting - then posts each result to its owner's mailbox; the owner picks it up at
+// its next poll and continues its walk. Every ray still sees its own leaf tests in its own order with the same
+// arithmetic, so results are unchanged. LDS protocol (all accesses volatile; one wave's LDS operations execute
+// in order, and the LDS serialises operations of different waves):
+//   producer: request words -> atomicAdd(reserved, n) -> ring[pos] = tid
+//   consumer: CAS(head, h, h + k) with k <= reserved - h -> spin until ring[pos] != EMPTY -> ring[pos] = EMPTY
+//             -> result words -> flag[owner] = 1
+//   owner:    flag[tid] == 1 -> read result -> flag[tid] = 0
+// A thread has at most one request outstanding, so 256 ring entries can never overflow.
+constexpr uint32_t kLeafQReqWords = 11;
+constexpr uint32_t kLeafQBytes = (kLeafQReqWords + 4 + 1 + 1) * 256 * 4 + 16;   // requests, results, flags, ring, {head, reserved}
+constexpr uint32_t kLeafQEmpty = 0xFFFFFFFFu;
 
 // Scheduling weights (quarter units, NODE/TRAVERSE weigh 4) and traversal-burst limits; the defaults
 // {5, 8, 12, 32, 2} are the measured optimum on the box scene (+-2 % plateau):
@@ -37,10 +54,10 @@ enum : uint32_t { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_GEN = 3, PH_FETCH =
 //   shadeAt, genAt   top-level vote: SHADE/GEN run when their weighted population exceeds (cN+cL)*4
 //   burst    at most this many NODE/LEAF steps before the wave re-votes
 //   keep8    ... or earlier, once fewer than keep8/8 of the lanes that started the burst still traverse
-struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, tradeAt; };
+struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, tradeAt, qPush = 4, qServe = 48; };
 
-template <bool STATS, bool LDS_NODES, int BLOCK, bool TWO_RAYS, int WAVES_PER_SIMD = 4>
-__global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK == 256 && WAVES_PER_SIMD > 4) ? WAVES_PER_SIMD : 1) path_trace_wavefront_kernel(DeviceScene sc, mi_trace_result* rays, uint32_t n,
+template <bool STATS, bool LDS_NODES, int BLOCK, bool TWO_RAYS, int WAVES_PER_SIMD = 4, bool LEAFQ = false>
+__global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK == 256 && (WAVES_PER_SIMD > 4 || LEAFQ)) ? WAVES_PER_SIMD : 1) path_trace_wavefront_kernel(DeviceScene sc, mi_trace_result* rays, uint32_t n,
                                                                    uint32_t* workCounter, uint32_t ldsNodeCount, WaveTune tune, uint32_t tileStreamW) {
   __shared__ float sinTbl[92];
   extern __shared__ __attribute__((aligned(16))) unsigned char dynLds[];
@@ -51,6 +68,18 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
     const uint4* src = reinterpret_cast<const uint4*>(sc.nodes);
     uint4* dst = reinterpret_cast<uint4*>(dynLds);
     for (uint32_t k = threadIdx.x; k < ldsNodeCount * 2; k += blockDim.x) dst[k] = src[k];
+    __syncthreads();
+  }
+
+  // LEAFQ: workgroup-shared request slots, mailboxes and ring (see the protocol above)
+  volatile uint32_t* qReq = reinterpret_cast<volatile uint32_t*>(dynLds);          // [word][tid]
+  volatile uint32_t* qRes = qReq + kLeafQReqWords * 256;                             // [4][tid]: t, b0, b1, b2
+  volatile uint32_t* qFlag = qRes + 4 * 256;
+  volatile uint32_t* qRing = qFlag + 256;
+  uint32_t* qCtr = const_cast<uint32_t*>(qRing + 256);                               // [0] head, [1] reserved
+  if (LEAFQ) {
+    qFlag[threadIdx.x] = 0u; qRing[threadIdx.x] = kLeafQEmpty;
+    if (threadIdx.x < 2) qCtr[threadIdx.x] = 0u;
     __syncthreads();
   }
 
@@ -140,6 +169,83 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
     __builtin_amdgcn_wave_barrier();
   }
 
+  // ---- LEAFQ operations ----
+  const uint32_t tid = threadIdx.x;
+  auto fu = [](float f) { return __float_as_uint(f); };
+  auto uf = [](uint32_t u) { return __uint_as_float(u); };
+  // lanes in PH_LEAF publish their request and start waiting
+  auto leafqPush = [&]() {
+    const unsigned long long m = __ballot(ph == PH_LEAF);
+    if (!m) return;
+    if (ph == PH_LEAF) {
+      if (STATS) cs.leaves++;
+      qReq[0 * 256 + tid] = fu(o.x); qReq[1 * 256 + tid] = fu(o.y); qReq[2 * 256 + tid] = fu(o.z);
+      qReq[3 * 256 + tid] = fu(d.x); qReq[4 * 256 + tid] = fu(d.y); qReq[5 * 256 + tid] = fu(d.z);
+      qReq[6 * 256 + tid] = fu(sh.sx); qReq[7 * 256 + tid] = fu(sh.sy); qReq[8 * 256 + tid] = fu(sh.sz);
+      qReq[9 * 256 + tid] = sh.kz; qReq[10 * 256 + tid] = pendLeaf;
+    }
+    const uint32_t first = (uint32_t)__ffsll((long long)m) - 1u;
+    uint32_t base = 0;
+    if (lane == first) base = atomicAdd(&qCtr[1], (uint32_t)__popcll(m));
+    base = __shfl(base, first);
+    if (ph == PH_LEAF) {
+      qRing[(base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & 255u] = tid;
+      ph = PH_WAIT;
+    }
+  };
+  // claim up to 64 requests (a full batch, or whatever is there when `force`) and run them, one per lane
+  auto leafqServe = [&](bool force) -> bool {
+    uint32_t h = 0, want = 0;
+    if (lane == 0) {
+      h = *reinterpret_cast<volatile uint32_t*>(&qCtr[0]);
+      const uint32_t avail = *reinterpret_cast<volatile uint32_t*>(&qCtr[1]) - h;
+      want = avail >= tune.qServe ? min(avail, 64u) : (force ? min(avail, 64u) : 0u);
+      if (want && atomicCAS(&qCtr[0], h, h + want) != h) want = 0;
+    }
+    h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
+    want = (uint32_t)__builtin_amdgcn_readfirstlane((int)want);
+    if (!want) return false;
+    if (STATS) { itL++; lnL += want; }
+    if (lane < want) {
+      const uint32_t slot = (h + lane) & 255u;
+      uint32_t owner;
+      do { owner = qRing[slot]; } while (owner == kLeafQEmpty);      // its producer is between reserve and write
+      qRing[slot] = kLeafQEmpty;
+      const f3 ro = mk(uf(qReq[0 * 256 + owner]), uf(qReq[1 * 256 + owner]), uf(qReq[2 * 256 + owner]));
+      const f3 rd = mk(uf(qReq[3 * 256 + owner]), uf(qReq[4 * 256 + owner]), uf(qReq[5 * 256 + owner]));
+      Shear rs; rs.sx = uf(qReq[6 * 256 + owner]); rs.sy = uf(qReq[7 * 256 + owner]); rs.sz = uf(qReq[8 * 256 + owner]);
+      rs.kz = qReq[9 * 256 + owner];
+      const GLeaf L = sc.leaves[qReq[10 * 256 + owner]];
+      float t, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+      const uint32_t kind = leaf_kind(L);
+      if (kind == LEAF_TRI) {
+        t = intersect_triangle(mk(L.f[0], L.f[1], L.f[2]), mk(L.f[3], L.f[4], L.f[5]), mk(L.f[6], L.f[7], L.f[8]), ro, rs, b0, b1, b2);
+        if (!(t > 0.f && t < kInf)) t = 0.f;                         // Mesh.hpp:93: not a candidate
+      } else if (kind == LEAF_SPHERE) {
+        t = intersect_sphere(L, ro, rd, 0.f);
+      } else {
+        t = intersect_disc(L, ro, rd);
+      }
+      qRes[0 * 256 + owner] = fu(t);
+      if (sc.hasNormals) { qRes[1 * 256 + owner] = fu(b0); qRes[2 * 256 + owner] = fu(b1); qRes[3 * 256 + owner] = fu(b2); }
+      qFlag[owner] = 1u;
+    }
+    return true;
+  };
+  // waiting lanes whose mailbox is full apply the result (CompactBvh.hpp:124) and walk on
+  auto leafqPoll = [&]() {
+    if (ph == PH_WAIT && qFlag[tid] != 0u) {
+      const float t = uf(qRes[0 * 256 + tid]);
+      if (t > 0.f && t < hit.t) {
+        hit.t = t; hit.leaf = pendLeaf;
+        if (sc.hasNormals) { hit.b0 = uf(qRes[1 * 256 + tid]); hit.b1 = uf(qRes[2 * 256 + tid]); hit.b2 = uf(qRes[3 * 256 + tid]); }
+      }
+      qFlag[tid] = 0u;
+      node = node + 1;
+      ph = (node >= numNodes) ? PH_SHADE : PH_NODE;
+    }
+  };
+
   for (;;) {
     // ---------------- FETCH: cheap, always served first ----------------
     const unsigned long long mF = __ballot(ph == PH_FETCH);
@@ -186,6 +292,20 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
       tN += (uint32_t)__popcll(__ballot(phB == PH_NODE)); tL += (uint32_t)__popcll(__ballot(phB == PH_LEAF));
       tS += (uint32_t)__popcll(__ballot(phB == PH_SHADE)); tG += (uint32_t)__popcll(__ballot(phB == PH_GEN));
     }
+    if (LEAFQ) {
+      const uint32_t cW = (uint32_t)__popcll(__ballot(ph == PH_WAIT));
+      if (cW > 0) {
+        if ((tN | tL | tS | tG) == 0) {
+          // nothing to run but rays waiting for primitive tests: serve whatever is queued (possibly our own)
+          if (!leafqServe(true)) __builtin_amdgcn_s_sleep(1);
+          leafqPoll();
+          continue;
+        }
+        leafqServe(false);
+        leafqPoll();
+        cN = tN = (uint32_t)__popcll(__ballot(ph == PH_NODE)); cS = tS = (uint32_t)__popcll(__ballot(ph == PH_SHADE));
+      }
+    }
     if ((tN | tL | tS | tG) == 0) break;            // every ray DONE (FETCH lanes were just served)
     // Top-level vote: TRAVERSE (the NODE and LEAF populations together) against SHADE and GEN, by weighted
     // population (a phase cannot use more than 64 lanes). Inside TRAVERSE a two-way mini-vote (two ballots)
@@ -214,7 +334,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
       bool anyExact = __ballot(exactSlab) != 0ull;
       for (;;) {
         const uint32_t stay = cN;
-        if (cN * 4u >= cL * tune.leafAt && cN > 0) {
+        if (LEAFQ ? (cN > 0) : (cN * 4u >= cL * tune.leafAt && cN > 0)) {
           // NODE: one box test per lane
           if (STATS) { itN++; lnN += stay; }
           if (ph == PH_NODE) {
@@ -254,6 +374,8 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
               if (node >= numNodes) ph = PH_SHADE;
             }
           }
+        } else if (LEAFQ) {
+          // (LEAFQ housekeeping follows the NODE step below)
         } else {
           // LEAF: one primitive test per lane
           if (STATS) { itL++; lnL += cL; }
@@ -280,6 +402,16 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
         }
         cN = (uint32_t)__popcll(__ballot(ph == PH_NODE));
         cL = (uint32_t)__popcll(__ballot(ph == PH_LEAF));
+        if (LEAFQ) {
+          // hand the LEAF lanes' primitive tests to the workgroup's queue once a few have gathered (or nothing else
+          // is left to do), run a batch if the queue holds one, and let waiting lanes pick up finished tests
+          if (cL >= tune.qPush || (cL > 0 && cN == 0)) { leafqPush(); leafqServe(false); cL = 0; }
+          if (__ballot(ph == PH_WAIT)) {
+            if (cN == 0) leafqServe(true);
+            leafqPoll();
+            cN = (uint32_t)__popcll(__ballot(ph == PH_NODE));
+          }
+        }
         if (TWO_RAYS && 64u - (cN + cL) >= tune.tradeAt) {
           // enough idle lanes: refill them from the parked rays that are mid-traversal
           phB = pph[lane];

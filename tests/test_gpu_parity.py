@@ -83,12 +83,12 @@ def test_traversal_visits_exactly_the_reference_nodes(scenes, monkeypatch):
 # ------------------------------------------------------------------------------------------------------
 # path trace: rgb sums + last-sample hit records, per-pixel RNG streams
 # ------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("kernel", ["0", "1", "1w4", "2", "3"])
+@pytest.mark.parametrize("kernel", ["0", "1", "1w4", "2", "3", "4", "4w4"])
 @pytest.mark.parametrize("name,size,spp", [("box-simple", 128, 32), ("box", 160, 24), ("spheres", 128, 32)])
 def test_path_trace_bit_exact(scenes, name, size, spp, kernel, monkeypatch):
     """kernel 0 = nested-loop kernel, 1 = phase-scheduled persistent kernel, 2 = the same with the BVH
     prefix staged in LDS, 3 = two rays per lane (second one parked in LDS); 1 is built for 5 waves per SIMD
-    (default) and for 4 ("1w4"). All of them must reproduce the oracle bit for bit."""
+    (default) and for 4 ("1w4"); 4 = primitive tests pooled across the workgroup through an LDS queue. All of them must reproduce the oracle bit for bit."""
     monkeypatch.setenv("MI_RAYLIB_KERNEL", kernel[0])
     monkeypatch.setenv("MI_RAYLIB_WAVES", "4" if kernel.endswith("w4") else "5")
     s = scenes[name]
