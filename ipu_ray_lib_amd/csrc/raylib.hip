@@ -239,10 +239,11 @@ constexpr uint32_t kLdsBudgetBytes = 160 * 1024 - 1024;     // 160 KiB per CU mi
 template <bool STATS>
 void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStream_t stream, int slot) {
   uint32_t* workCounter = S.d_workCounter + slot;
-  // raster streams (the whole window in one launch) are walked in 8x8 pixel tiles
-  const uint32_t w = (uint32_t)S.params.window_w, h = (uint32_t)S.params.window_h;
+  // Streams are walked in 8x8 pixel tiles of window-width rows (a whole window, a batch of it, or one rank's
+  // 8-row bands are all sequences of full rows); the walk is only a work ORDER, any stream stays correct.
+  const uint32_t w = (uint32_t)S.params.window_w;
   static const bool noTiles = getenv("MI_RAYLIB_NO_TILES") != nullptr;
-  const uint32_t tileW = (!noTiles && w >= 8 && h >= 8 && (w % 8) == 0 && (h % 8) == 0 && (uint64_t)w * h == cnt) ? w : 0u;
+  const uint32_t tileW = (!noTiles && w >= 8 && (w % 8) == 0 && cnt >= 8u * w) ? w : 0u;
   HIP_CHECK(hipMemsetAsync(workCounter, 0, sizeof(uint32_t), stream));
   if (g_kernelChoice == 2 && S.ds.numNodes > 0) {
     // one 1024-thread workgroup per CU shares one LDS copy of the first nodes of the (preorder) array

@@ -84,6 +84,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
   }
 
   const uint32_t lane = threadIdx.x & 63;
+  const uint32_t tiledCount = tileStreamW ? (n / (8u * tileStreamW)) * (8u * tileStreamW) : 0u;
   const uint32_t numNodes = sc.numNodes;
   const uint32_t spp = sc.samplesPerPixel;
 
@@ -256,11 +257,12 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
       if (ph == PH_FETCH) {
         const uint32_t idx = base + (uint32_t)__popcll(mF & ((1ull << lane) - 1ull));
         if (idx < n) {
-          // When the stream is a raster of width tileStreamW (multiple of 8, height too), consecutive work
-          // indices walk 8x8 pixel tiles, so the 64 pixels a wave starts with are a compact tile whose
-          // primary rays traverse alike. Any order gives the same image: every pixel owns its RNG stream.
+          // When the stream is made of full rows of width tileStreamW (a multiple of 8), consecutive work indices
+          // walk 8x8 pixel tiles over each complete group of 8 rows (the remainder keeps stream order), so the
+          // 64 pixels a wave starts with are a compact tile whose primary rays traverse alike. The map is a
+          // bijection on [0, n) and any order gives the same image: every pixel owns its RNG stream.
           uint32_t entry = idx;
-          if (tileStreamW) {
+          if (tileStreamW && idx < tiledCount) {
             const uint32_t t = idx >> 6, within = idx & 63u, perRow = tileStreamW >> 3;
             entry = ((t / perRow) * 8u + (within >> 3)) * tileStreamW + (t % perRow) * 8u + (within & 7u);
           }

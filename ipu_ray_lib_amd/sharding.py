@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import numpy as np
 
-TILE_ROWS = 16
+TILE_ROWS = 8      # = the height of the 8x8 work tiles; 2880 rows / 8 = 360 bands = 45 per rank at 8 GPUs (16-row bands: 22.5)
 
 
 def rank_pixels(width: int, height: int, rank: int, world: int, tile_rows: int = TILE_ROWS):

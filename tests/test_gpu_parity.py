@@ -525,3 +525,28 @@ def test_scene_from_serialised_blob_renders_identically(scenes):
         assert got.tobytes() == want.tobytes()
     with pytest.raises(irl.RaylibError, match="end of byte stream"):
         irl.IpuScene.from_blob(blob[: blob.size // 2].copy(), extras)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rank_streams_render_like_the_whole_frame(scenes, world):
+    """The multi-GPU decomposition on one GPU: each rank's stream (8-row bands, round-robin; ragged for world=3)
+    rendered separately - with the 8x8 tile work order applied to a stream that is NOT the whole window - and
+    scattered back equals the whole-frame render and the oracle bit for bit (per-pixel RNG streams)."""
+    from ipu_ray_lib_amd import sharding
+    s = scenes["box"]; d = s.desc
+    w, h = 128, 112
+    d.set_image(w, h); d.samples_per_pixel = 6; d.path_trace = 1
+    whole = s.init_ray_stream(); want = whole.copy()
+    dev = irl.IpuScene(d)
+    dev.run(whole, irl.MODE_PATH_TRACE)
+    ol.path_trace_pixel_rng(d, want, 16)
+    assert_streams_identical(whole, want, "whole frame")
+    frame = np.zeros_like(whole)
+    for rank in range(world):
+        rows, cols = sharding.rank_pixels(w, h, rank, world)
+        part = whole.copy()[:rows.size]
+        part[:] = s.init_ray_stream()[rows * w + cols]
+        dev.run(part, irl.MODE_PATH_TRACE)
+        frame[rows * w + cols] = part
+    assert_streams_identical(frame, want, f"{world} rank streams")
+    dev.close()
