@@ -34,9 +34,14 @@ PMC_SUMMARY = ROOT / "profiles" / "r01_pmc_hbm_summary.json"   # HBM bytes per l
 
 
 def image_shape(n_gpus: int, base: int):
-    """Weak scaling: N x base^2 pixels. 1:1x1, 2:2x1, 4:2x2, 8:4x2 (width x height multiples)."""
-    kx, ky = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}.get(n_gpus, (n_gpus, 1))
-    return base * kx, base * ky
+    """Weak scaling: the SAME square view at about N x base^2 pixels (edge = base*sqrt(N) rounded to the nearest
+    multiple of 8N, so that the 8-row shard bands divide evenly among the ranks): 1440, 2032, 2880, 4096 for
+    N = 1, 2, 4, 8. A square frame keeps the image content - and with it casts per path - the same for every N;
+    a 2:1 frame of the Cornell box sees mostly empty space beside the box and measures a different workload
+    (1.98 instead of 2.97 casts per path, tools/rank_probe.py)."""
+    step = 8 * n_gpus
+    edge = max(step, int(round(base * (n_gpus ** 0.5) / step)) * step)
+    return edge, edge
 
 
 def make_stream(irl, scene, rows, cols):
@@ -192,7 +197,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic (built-in Cornell box + monkey bust scene, seeded per-pixel RNG streams)",
         "config": {"workload": f"built-in scene '{args.scene}', path-trace {width}x{height} x {args.spp} spp, max path length 10, "
-                               f"roulette depth 3, AA 0.25, seed 1442, {args.size}x{args.size} pixels per GPU",
+                               f"roulette depth 3, AA 0.25, seed 1442, {n} pixels on rank 0",
                    "parallelism": f"ray tiles x{world}" + (" + 1 RCCL gather/frame" if world > 1 else "")},
         "paths_per_s": total_paths / elapsed,
         "ms_per_frame": elapsed / max(args.steps, 1) * 1e3,
