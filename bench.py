@@ -87,10 +87,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    # Native libraries travel prebuilt; if anything is missing or stale only ONE process per node rebuilds it
     import __graft_entry__ as ge
-    ge.build_cpu()
-    if not (ROOT / "ipu_ray_lib_amd" / "libmi_raylib.so").exists():
-        ge.build_device()
+    if local_rank == 0:
+        ge.build_cpu()
+        if not (ROOT / "ipu_ray_lib_amd" / "libmi_raylib.so").exists():
+            ge.build_device()
+    if dist is not None:
+        dist.barrier()
 
     width, height = image_shape(world, args.size)
     scene = irl.HostScene.builtin(args.scene)
