@@ -213,7 +213,7 @@ template <uint32_t TN, uint32_t MT>
 __device__ __forceinline__ void nif_dense_layer(const NifParams& P, const NifLayerDesc& L, bool last, _Float16* X, uint32_t stride,
                                                 uint32_t rowBase, uint32_t ng, uint32_t lane, const h8* __restrict__ weights,
                                                 const float* __restrict__ bias, uint32_t row0, uint32_t total,
-                                                const uint32_t* __restrict__ idx, float* __restrict__ bgrOut, mi_trace_result* rays) {
+                                                const uint32_t* __restrict__ idx, float* __restrict__ bgrOut, mi_trace_result* rays, bool scatter) {
   f4v acc[TN][MT];
   // The accumulators start from the bias: it is the C operand of the first k-step's MFMAs (no zero fill, no bias add).
   f4v bv[TN];
@@ -321,7 +321,7 @@ __device__ __forceinline__ void nif_dense_layer(const NifParams& P, const NifLay
             if (P.logTonemap) o[c] = expf(o[c]);
           }
           const uint32_t row = row0 + r;
-          if (bgrOut) { bgrOut[3 * row] = o[0]; bgrOut[3 * row + 1] = o[1]; bgrOut[3 * row + 2] = o[2]; }
+          if (bgrOut) { const size_t dst = scatter ? (size_t)idx[row] : (size_t)row; bgrOut[3 * dst] = o[0]; bgrOut[3 * dst + 1] = o[1]; bgrOut[3 * dst + 2] = o[2]; }
           if (rays) {
             mi_trace_result* res = rays + (idx ? idx[row] : row);
             const mi_vec3 tp = res->h.throughput;
@@ -344,7 +344,7 @@ template <uint32_t TILES, uint32_t MT, uint32_t RG>
 __global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : (MT == 4 && RG == 1) ? 3 : 1) nif_mlp_kernel(NifParams P, const h8* __restrict__ weights, const float* __restrict__ bias,
                                                       const float* __restrict__ u, const float* __restrict__ v,
                                                       const uint32_t* __restrict__ idx, const uint32_t* __restrict__ countPtr,
-                                                      uint32_t numRows, float* __restrict__ bgrOut, mi_trace_result* rays) {
+                                                      uint32_t numRows, float* __restrict__ bgrOut, mi_trace_result* rays, bool scatter) {
   constexpr uint32_t kNifRows = 16u * MT * RG;                    // rays per workgroup pass
   extern __shared__ __attribute__((aligned(16))) _Float16 X[];   // [kNifRows][P.stride]
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : (MT == 4 
       const NifLayerDesc L = P.layers[l];
       const bool last = (l + 1 == P.numLayers);
       const uint32_t tilesLayer = L.nTiles >> 2;            // tiles per wave in this layer (wave-uniform)
-#define MI_NIF_LAYER(TN) nif_dense_layer<TN, MT>(P, L, last, X, stride, rowBase, ng, lane, weights, bias, row0, total, idx, bgrOut, rays)
+#define MI_NIF_LAYER(TN) nif_dense_layer<TN, MT>(P, L, last, X, stride, rowBase, ng, lane, weights, bias, row0, total, idx, bgrOut, rays, scatter)
       if (tilesLayer == TILES) MI_NIF_LAYER(TILES);
       else if (TILES > 1 && tilesLayer == 1) MI_NIF_LAYER(1);
       else if (TILES > 2 && tilesLayer == 2) MI_NIF_LAYER(2);
@@ -394,8 +394,9 @@ __global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : (MT == 4 
   }
 }
 
+// bgrOut: result of row r at bgrOut[3r..] - or, with `scatter`, at bgrOut[3*idx[r]..] (the row's own slot)
 inline void nif_launch_mlp(const NifDevice& nif, const float* u, const float* v, const uint32_t* idx, const uint32_t* countPtr,
-                           uint32_t numRows, float* bgrOut, mi_trace_result* rays, hipStream_t stream) {
+                           uint32_t numRows, float* bgrOut, mi_trace_result* rays, hipStream_t stream, bool scatter = false) {
   if (numRows == 0) return;
   uint32_t maxTiles = 1;
   for (uint32_t l = 0; l < nif.p.numLayers; ++l) maxTiles = std::max(maxTiles, nif.p.layers[l].nTiles / 4);
@@ -410,7 +411,7 @@ inline void nif_launch_mlp(const NifDevice& nif, const float* u, const float* v,
     uint32_t blocks = (numRows + rowsPerPass - 1) / rowsPerPass;
     if (blocks > 256 * 8) blocks = 256 * 8;          // grid-stride beyond 8 passes per CU
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNifMaxLdsBytes);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, nif.p, nif.d_weights, nif.d_bias, u, v, idx, countPtr, numRows, bgrOut, rays);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, nif.p, nif.d_weights, nif.d_bias, u, v, idx, countPtr, numRows, bgrOut, rays, scatter);
   };
   if (mt == 6 && rg == 2) {
     if (maxTiles <= 2) launch(nif_mlp_kernel<2, 6, 2>, 192, 512);
@@ -433,6 +434,26 @@ inline void nif_launch_mlp(const NifDevice& nif, const float* u, const float* v,
     else if (maxTiles <= 5) launch(nif_mlp_kernel<5, 4, 2>, 128, 512);
     else launch(nif_mlp_kernel<6, 4, 2>, 128, 512);
   }
+}
+
+// Replays the reference's per-sample order for one launch of `samples` slots per pixel (trace_wavefront.hpp,
+// WaveExtras): rgb += color of the sample's path (codelets/TraceCodelets.cpp:262), then, if it escaped,
+// rgb += throughput * env with BGR -> RGB (PostProcessEscapedRays, codelets :361-382).
+__global__ void __launch_bounds__(256) nif_accumulate_kernel(mi_trace_result* rays, uint32_t n, uint32_t samples, const float* __restrict__ color,
+                                                             const float* __restrict__ tp, const float* __restrict__ u, const float* __restrict__ bgr) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  mi_vec3 rgb = rays[i].rgb;
+  for (uint32_t s = 0; s < samples; ++s) {
+    const size_t q = (size_t)s * n + i;
+    rgb.x += color[3 * q]; rgb.y += color[3 * q + 1]; rgb.z += color[3 * q + 2];
+    if (u[q] >= 0.f) {
+      rgb.x += tp[3 * q] * bgr[3 * q + 2];
+      rgb.y += tp[3 * q + 1] * bgr[3 * q + 1];
+      rgb.z += tp[3 * q + 2] * bgr[3 * q];
+    }
+  }
+  rays[i].rgb = rgb;
 }
 
 // mi_nif_infer_device: every row is evaluated (no compaction)

@@ -86,6 +86,7 @@ struct mi_scene {
   NifDevice nif;
   // scratch for the per-sample NIF loop
   Rng* d_rng = nullptr; float* d_u = nullptr; float* d_v = nullptr; float* d_bgr = nullptr; size_t scratchRays = 0;
+  float* d_slotColor = nullptr; float* d_slotTp = nullptr;   // NIF renders: per-(sample, pixel) slots of one launch
 
   ~mi_scene() {
     (void)hipSetDevice(device);
@@ -94,6 +95,8 @@ struct mi_scene {
     if (d_u) (void)hipFree(d_u);
     if (d_v) (void)hipFree(d_v);
     if (d_bgr) (void)hipFree(d_bgr);
+    if (d_slotColor) (void)hipFree(d_slotColor);
+    if (d_slotTp) (void)hipFree(d_slotTp);
     nif.release();
   }
   template <class T> T* keep(T* p) { if (p) allocations.push_back((void*)p); return p; }
@@ -215,17 +218,25 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
   S.keep(S.d_workCounter);
 }
 
+uint32_t kNifSamplesPerLaunch = 16;  // slots per pixel per launch in NIF renders (44 B each); MI_RAYLIB_NIF_SPL overrides (1..64)
+
 void ensureScratch(mi_scene& S, size_t n) {
+  if (const char* e = getenv("MI_RAYLIB_NIF_SPL")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v <= 64 && v != kNifSamplesPerLaunch) { kNifSamplesPerLaunch = v; S.scratchRays = 0; } }
   if (S.scratchRays >= n) return;
   if (S.d_rng) (void)hipFree(S.d_rng);
   if (S.d_u) (void)hipFree(S.d_u);
   if (S.d_v) (void)hipFree(S.d_v);
   if (S.d_bgr) (void)hipFree(S.d_bgr);
-  S.d_rng = nullptr; S.d_u = S.d_v = S.d_bgr = nullptr; S.scratchRays = 0;
+  if (S.d_slotColor) (void)hipFree(S.d_slotColor);
+  if (S.d_slotTp) (void)hipFree(S.d_slotTp);
+  S.d_rng = nullptr; S.d_u = S.d_v = S.d_bgr = S.d_slotColor = S.d_slotTp = nullptr; S.scratchRays = 0;
+  const size_t slots = n * kNifSamplesPerLaunch;
   HIP_CHECK(hipMalloc(&S.d_rng, n * sizeof(Rng)));
-  HIP_CHECK(hipMalloc(&S.d_u, n * sizeof(float)));
-  HIP_CHECK(hipMalloc(&S.d_v, n * sizeof(float)));
-  HIP_CHECK(hipMalloc(&S.d_bgr, 3 * n * sizeof(float)));
+  HIP_CHECK(hipMalloc(&S.d_u, slots * sizeof(float)));
+  HIP_CHECK(hipMalloc(&S.d_v, slots * sizeof(float)));
+  HIP_CHECK(hipMalloc(&S.d_bgr, 3 * slots * sizeof(float)));
+  HIP_CHECK(hipMalloc(&S.d_slotColor, 3 * slots * sizeof(float)));
+  HIP_CHECK(hipMalloc(&S.d_slotTp, 3 * slots * sizeof(float)));
   S.scratchRays = n;
 }
 
@@ -236,8 +247,15 @@ int g_wavesPerSimd = 5;          // MI_RAYLIB_WAVES=4: the 108-VGPR build of the
 
 constexpr uint32_t kLdsBudgetBytes = 160 * 1024 - 1024;     // 160 KiB per CU minus the static allocations
 
+// Workgroups of 256 threads that are resident at once with `perSimd` waves per SIMD (4 SIMDs per CU).
+uint32_t residentBlocks(const mi_scene& S, uint32_t perSimd) {
+  static int cus = 0;
+  if (!cus) { hipDeviceProp_t p; cus = (hipGetDeviceProperties(&p, S.device) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+  return (uint32_t)cus * perSimd;
+}
+
 template <bool STATS>
-void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStream_t stream, int slot) {
+void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStream_t stream, int slot, const WaveExtras& ex = WaveExtras{}) {
   uint32_t* workCounter = S.d_workCounter + slot;
   // Streams are walked in 8x8 pixel tiles of window-width rows (a whole window, a batch of it, or one rank's
   // 8-row bands are all sequences of full rows); the walk is only a work ORDER, any stream stays correct.
@@ -245,7 +263,8 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
   static const bool noTiles = getenv("MI_RAYLIB_NO_TILES") != nullptr;
   const uint32_t tileW = (!noTiles && w >= 8 && (w % 8) == 0 && cnt >= 8u * w) ? w : 0u;
   HIP_CHECK(hipMemsetAsync(workCounter, 0, sizeof(uint32_t), stream));
-  if (g_kernelChoice == 2 && S.ds.numNodes > 0) {
+  const bool plain = ex.rngState == nullptr;      // the sample-at-a-time form only exists for the default kernel
+  if (plain && g_kernelChoice == 2 && S.ds.numNodes > 0) {
     // one 1024-thread workgroup per CU shares one LDS copy of the first nodes of the (preorder) array
     const uint32_t ldsNodes = std::min<uint32_t>(S.ds.numNodes, kLdsBudgetBytes / (uint32_t)sizeof(GNode));
     const size_t ldsBytes = (size_t)ldsNodes * sizeof(GNode);
@@ -253,26 +272,27 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
     static bool attrSet = false;
     if (!attrSet) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes)); attrSet = true; }
     const uint32_t blocks = std::min<uint32_t>((cnt + 1023) / 1024, 256);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, ldsNodes, g_tune, tileW);
-  } else if (g_kernelChoice == 3 && !S.ds.hasNormals) {
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, ldsNodes, g_tune, tileW, ex);
+  } else if (plain && g_kernelChoice == 3 && !S.ds.hasNormals) {
     // two rays per lane, the second parked in LDS: 9 uint4 groups x 64 lanes x 4 waves = 36 KiB per workgroup
     const size_t ldsBytes = (size_t)kParkBytesPerWave * (256 / 64);
     const uint32_t blocks = std::min<uint32_t>((cnt + 511) / 512, 256 * 4);
-    hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, true>), dim3(blocks), dim3(256), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW);
+    hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, true>), dim3(blocks), dim3(256), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, ex);
   } else if (g_kernelChoice == 4) {
     // primitive tests pooled across the workgroup (LEAFQ): 17 KiB of LDS per workgroup
-    const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, 256 * 8);
-    if (!STATS && g_wavesPerSimd == 5)
-      hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, false, 5, true>), dim3(blocks), dim3(256), kLeafQBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW);
+    const bool five = !STATS && g_wavesPerSimd == 5;
+    const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, ex.staticFetch ? residentBlocks(S, five ? 5 : 4) : 256 * 8);
+    if (five)
+      hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, false, 5, true>), dim3(blocks), dim3(256), kLeafQBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, ex);
     else
-      hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, false, 4, true>), dim3(blocks), dim3(256), kLeafQBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW);
+      hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, false, 4, true>), dim3(blocks), dim3(256), kLeafQBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, ex);
   } else if (!STATS && g_wavesPerSimd == 5) {
     // 96-VGPR build: 5 waves per SIMD (+4.6 % on the box scene; 6 waves = 80 VGPRs spills in the hot loop: -9 %)
-    const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, 256 * 8);
-    hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, false, 5>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW);
+    const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, ex.staticFetch ? residentBlocks(S, 5) : 256 * 8);   // fixed shares: resident workgroups only
+    hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, false, 5>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, ex);
   } else {
-    const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, 256 * 8);
-    hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, false>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW);
+    const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, ex.staticFetch ? residentBlocks(S, 4) : 256 * 8);
+    hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, false>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, ex);
   }
 }
 
@@ -298,10 +318,30 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
       // Repeat(spp){ trace 1 sample; uv pre-pass; NIF; env post-pass }  (src/IpuScene.cpp:571-583)
       ensureScratch(S, n);
       const float radians = (S.hdriRotationDegrees / 360.f) * (float)(2.0 * M_PI);   // src/IpuScene.cpp:644
-      for (uint32_t s = 0; s < S.ds.samplesPerPixel; ++s) {
-        if (g_fullStats) hipLaunchKernelGGL(path_trace_kernel<true>, grid, block, 0, stream, S.ds, d_rays, cnt, s, 1u, S.d_rng);
-        else hipLaunchKernelGGL(path_trace_kernel<false>, grid, block, 0, stream, S.ds, d_rays, cnt, s, 1u, S.d_rng);
-        nif_env_pass(S.nif, d_rays, cnt, radians, S.d_u, S.d_v, S.d_bgr, S.maxNifBatch, stream);
+      const bool wave = g_kernelChoice != 0 && S.ds.maxPathLength >= 1;
+      if (wave) {
+        // persistent phase-scheduled kernel, several samples per launch; every path leaves a slot (WaveExtras), the
+        // MLP runs on the compacted escaped slots, and a per-pixel pass adds everything in the reference's order
+        if ((uint64_t)cnt * kNifSamplesPerLaunch > 0xFFFFFFFFull) throw ArgError("mi_render: ray batch too large for a NIF render (cut it with mi_scene_set_ray_batch)");
+        S.nif.ensureIndex((size_t)cnt * kNifSamplesPerLaunch);
+        for (uint32_t s0 = 0; s0 < S.ds.samplesPerPixel; s0 += kNifSamplesPerLaunch) {
+          const uint32_t sc = std::min<uint32_t>(kNifSamplesPerLaunch, S.ds.samplesPerPixel - s0);
+          HIP_CHECK(hipMemsetAsync(S.nif.d_count, 0, sizeof(uint32_t), stream));
+          WaveExtras ex;
+          ex.rngState = S.d_rng; ex.seedNow = (s0 == 0) ? 1u : 0u; ex.sampleCount = sc;
+          ex.u = S.d_u; ex.v = S.d_v; ex.slotColor = S.d_slotColor; ex.slotTp = S.d_slotTp;
+          ex.index = S.nif.d_index; ex.count = S.nif.d_count; ex.azimuthRotation = radians;
+          if (g_fullStats) launchWavefront<true>(S, d_rays, cnt, stream, slot, ex);
+          else launchWavefront<false>(S, d_rays, cnt, stream, slot, ex);
+          nif_launch_mlp(S.nif, S.d_u, S.d_v, S.nif.d_index, S.nif.d_count, cnt * sc, S.d_bgr, nullptr, stream, true);
+          hipLaunchKernelGGL(nif_accumulate_kernel, grid, block, 0, stream, d_rays, cnt, sc, S.d_slotColor, S.d_slotTp, S.d_u, S.d_bgr);
+        }
+      } else {
+        for (uint32_t s = 0; s < S.ds.samplesPerPixel; ++s) {
+          if (g_fullStats) hipLaunchKernelGGL(path_trace_kernel<true>, grid, block, 0, stream, S.ds, d_rays, cnt, s, 1u, S.d_rng);
+          else hipLaunchKernelGGL(path_trace_kernel<false>, grid, block, 0, stream, S.ds, d_rays, cnt, s, 1u, S.d_rng);
+          nif_env_pass(S.nif, d_rays, cnt, radians, S.d_u, S.d_v, S.d_bgr, S.maxNifBatch, stream);
+        }
       }
     }
   } else {

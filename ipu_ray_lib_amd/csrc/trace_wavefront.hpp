@@ -56,9 +56,31 @@ constexpr uint32_t kLeafQEmpty = 0xFFFFFFFFu;
 //   keep8    ... or earlier, once fewer than keep8/8 of the lanes that started the burst still traverse
 struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, tradeAt, qPush = 4, qServe = 48; };
 
+// Per-launch extras for renders with the NIF environment. The reference traces ONE sample, evaluates the
+// environment for the rays that escaped, adds it, and repeats (src/IpuScene.cpp:571-583). One sample per launch
+// leaves the GPU waiting for the longest path of every wave (0.6 ms per launch on one MI355X whatever the pixel
+// count), so sampleCount samples are traced per launch and each path leaves a SLOT q = sample * n + pixel:
+// its radiance `color`, and - if it escaped - throughput and environment coordinates (PreProcessEscapedRays,
+// codelets/TraceCodelets.cpp:321-358; u = -1 marks "did not escape") plus q appended to the compacted list the
+// MLP consumes. A per-pixel pass then replays the reference's order exactly: for each sample rgb += color, then
+// rgb += throughput * env (nif_accumulate_kernel). The per-pixel RNG streams persist in rngState between launches.
+// All-null extras = the plain multi-sample launch (rgb accumulated in registers).
+struct WaveExtras {
+  Rng* rngState = nullptr;       // [n] per ray; loaded at FETCH unless seedNow, stored when the launch's samples are done
+  uint32_t seedNow = 1;
+  uint32_t sampleCount = 0;      // 0 = scene's samplesPerPixel
+  float* u = nullptr; float* v = nullptr;          // [sampleCount][n]
+  float* slotColor = nullptr; float* slotTp = nullptr;   // [sampleCount][n][3]
+  uint32_t* index = nullptr; uint32_t* count = nullptr;
+  float azimuthRotation = 0.f;
+  uint32_t fetchChunk = 0;       // work indices taken per global atomic (multiple of 64; 0 = 64)
+  uint32_t staticFetch = 0;      // 1: fixed equal share per wave, no global work counter
+  uint32_t fetchAt = 0;          // lanes that must wait for a pixel before the wave pays for a fetch (0 = 1: serve at once)
+};
+
 template <bool STATS, bool LDS_NODES, int BLOCK, bool TWO_RAYS, int WAVES_PER_SIMD = 4, bool LEAFQ = false>
 __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK == 256 && (WAVES_PER_SIMD > 4 || LEAFQ)) ? WAVES_PER_SIMD : 1) path_trace_wavefront_kernel(DeviceScene sc, mi_trace_result* rays, uint32_t n,
-                                                                   uint32_t* workCounter, uint32_t ldsNodeCount, WaveTune tune, uint32_t tileStreamW) {
+                                                                   uint32_t* workCounter, uint32_t ldsNodeCount, WaveTune tune, uint32_t tileStreamW, WaveExtras ex) {
   __shared__ float sinTbl[92];
   extern __shared__ __attribute__((aligned(16))) unsigned char dynLds[];
   load_sin_table(sinTbl);
@@ -84,9 +106,19 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
   }
 
   const uint32_t lane = threadIdx.x & 63;
+  const uint32_t fetchChunk = ex.fetchChunk ? ex.fetchChunk : 64u, fetchAt = ex.fetchAt ? ex.fetchAt : 1u;
+  uint32_t chunkNext = 0, chunkEnd = 0;          // wave-uniform: the local range of work indices not handed out yet
+  if (ex.staticFetch) {
+    // One sample per launch: every wave takes a fixed, equal share of the stream (whole 8x8 tiles) instead of
+    // pulling from the global counter - at ~60 paths per service the counter's same-address atomics serialise in L2.
+    const uint32_t waves = gridDim.x * (BLOCK / 64), wid = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const uint32_t per = ((n + waves * 64u - 1u) / (waves * 64u)) * 64u;
+    chunkNext = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(wid * per, n));
+    chunkEnd = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(chunkNext + per, n));
+  }
   const uint32_t tiledCount = tileStreamW ? (n / (8u * tileStreamW)) * (8u * tileStreamW) : 0u;
   const uint32_t numNodes = sc.numNodes;
-  const uint32_t spp = sc.samplesPerPixel;
+  const uint32_t spp = ex.sampleCount ? ex.sampleCount : sc.samplesPerPixel;
 
   // ---- lane state ----
   uint32_t ph = PH_FETCH;
@@ -249,13 +281,31 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
 
   for (;;) {
     // ---------------- FETCH: cheap, always served first ----------------
-    const unsigned long long mF = __ballot(ph == PH_FETCH);
-    if (mF) {
-      uint32_t base = 0;
-      if (lane == (uint32_t)__ffsll((long long)mF) - 1) base = atomicAdd(workCounter, (uint32_t)__popcll(mF));
-      base = __shfl(base, __ffsll((long long)mF) - 1);
-      if (ph == PH_FETCH) {
-        const uint32_t idx = base + (uint32_t)__popcll(mF & ((1ull << lane) - 1ull));
+    // Work is taken from the global counter in chunks (ex.fetchChunk indices, a multiple of 64 = whole 8x8 tiles)
+    // and handed out to the lanes from the wave's local range: one global atomic per chunk, not per service.
+    for (;;) {
+      const unsigned long long mF = __ballot(ph == PH_FETCH);
+      if (!mF) break;
+      // Each service costs the wave a global round trip (counter, then the pixel record). With many samples per
+      // pixel that is rare and lanes are served at once; with one sample per launch every lane is back after a
+      // single path, so lanes wait until ex.fetchAt of them can be served together - unless nothing else can run.
+      if ((uint32_t)__popcll(mF) < fetchAt && __ballot(ph != PH_FETCH && ph != PH_DONE)) break;
+      if (chunkNext >= chunkEnd) {
+        if (ex.staticFetch) {                       // this wave's fixed share is used up
+          if (ph == PH_FETCH) ph = PH_DONE;
+          break;
+        }
+        const uint32_t firstF = (uint32_t)__ffsll((long long)mF) - 1u;
+        uint32_t base = 0;
+        if (lane == firstF) base = atomicAdd(workCounter, fetchChunk);
+        chunkNext = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(base, firstF));
+        chunkEnd = chunkNext + fetchChunk;
+      }
+      const uint32_t avail = chunkEnd - chunkNext, rankF = (uint32_t)__popcll(mF & ((1ull << lane) - 1ull));
+      const uint32_t chunkBase = chunkNext;
+      chunkNext += min((uint32_t)__popcll(mF), avail);
+      if (ph == PH_FETCH && rankF < avail) {
+        const uint32_t idx = chunkBase + rankF;
         if (idx < n) {
           // When the stream is made of full rows of width tileStreamW (a multiple of 8), consecutive work indices
           // walk 8x8 pixel tiles over each complete group of 8 rows (the remainder keeps stream order), so the
@@ -270,7 +320,8 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
           const mi_trace_result* res = rays + entry;
           prow = res->u; pcol = res->v;
           if (!TWO_RAYS) rgb = mk(res->rgb.x, res->rgb.y, res->rgb.z);   // TWO_RAYS accumulates rgb in memory
-          rng_seed_pixel(rng, sc.rngSeed, prow, pcol);
+          if (ex.rngState && !ex.seedNow) rng = ex.rngState[entry];
+          else rng_seed_pixel(rng, sc.rngSeed, prow, pcol);
           sample = 0;
           ph = PH_GEN;
         } else {
@@ -429,6 +480,8 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
       // ---------------- SHADE: traversal of bounce `bounce` is complete ----------------
       if (STATS) { itS++; lnS += cS; }
       const unsigned long long tq1 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+      bool envRay = false;          // this lane's path ended in this SHADE step by escaping (slot mode)
+      uint32_t envSlot = 0;
       if (ph == PH_SHADE) {
         bool terminated = false;
         if (hit.leaf != 0xFFFFFFFFu) {
@@ -472,14 +525,20 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
         if (bounce >= sc.maxPathLength) terminated = true;
         if (terminated) {
           mi_trace_result* res = rays + pix;
-          if (TWO_RAYS) { const mi_vec3 acc = res->rgb; res->rgb = {acc.x + color.x, acc.y + color.y, acc.z + color.z}; }
+          if (ex.slotColor) {
+            const size_t q = (size_t)sample * n + pix;
+            ex.slotColor[3 * q] = color.x; ex.slotColor[3 * q + 1] = color.y; ex.slotColor[3 * q + 2] = color.z;
+            envRay = (oFlags & MI_FLAG_ESCAPED) != 0;
+            envSlot = (uint32_t)q;
+            if (!envRay) ex.u[q] = -1.f;
+          } else if (TWO_RAYS) { const mi_vec3 acc = res->rgb; res->rgb = {acc.x + color.x, acc.y + color.y, acc.z + color.z}; }
           else rgb = rgb + color;
           ++paths;
           ++sample;
           if (sample < spp) ph = PH_GEN;
           else {
             // pixel complete: rgb sum + the LAST sample's hit record
-            if (!TWO_RAYS) res->rgb = {rgb.x, rgb.y, rgb.z};
+            if (!TWO_RAYS && !ex.slotColor) res->rgb = {rgb.x, rgb.y, rgb.z};
             uint32_t oPrim = MI_INVALID_PRIM, oGeom = MI_INVALID_GEOM;
             if (oLeaf != 0xFFFFFFFFu) { const GLeaf LL = sc.leaves[oLeaf]; oPrim = LL.primID; oGeom = leaf_geom(LL); }
             mi_hit_record hr;
@@ -490,6 +549,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
             hr.throughput = {tp.x, tp.y, tp.z};
             hr.geom_id = (uint16_t)oGeom; hr.flags = (uint16_t)oFlags;
             res->h = hr;
+            if (ex.rngState) ex.rngState[pix] = rng;
             ph = PH_FETCH;
           }
         } else {
@@ -502,6 +562,29 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
           node = 0;
           ++casts;
           ph = (numNodes > 0) ? PH_NODE : PH_SHADE;
+        }
+      }
+      if (ex.slotColor) {
+        const unsigned long long mE = __ballot(envRay);
+        if (mE) {
+          const uint32_t firstE = (uint32_t)__ffsll((long long)mE) - 1u;
+          uint32_t baseE = 0;
+          if (lane == firstE) baseE = atomicAdd(ex.count, (uint32_t)__popcll(mE));
+          baseE = __shfl(baseE, firstE);
+          if (envRay) {
+            // PreProcessEscapedRays (codelets/TraceCodelets.cpp:321-358), same arithmetic as escaped_uv_kernel
+            const float twoPi = (float)(2.0 * 3.14159265358979323846264338327950288);
+            const float invPi = (float)(1.0 / 3.14159265358979323846264338327950288);
+            const float inv2Pi = (float)(1.0 / (2.0 * 3.14159265358979323846264338327950288));
+            const float theta = acosf(d.y);
+            float phi = atan2f(d.z, d.x) + ex.azimuthRotation;
+            if (phi < 0.f) phi += twoPi;
+            else if (phi > twoPi) phi -= twoPi;
+            ex.u[envSlot] = theta * invPi;
+            ex.v[envSlot] = phi * inv2Pi;
+            ex.slotTp[3 * (size_t)envSlot] = tp.x; ex.slotTp[3 * (size_t)envSlot + 1] = tp.y; ex.slotTp[3 * (size_t)envSlot + 2] = tp.z;
+            ex.index[baseE + (uint32_t)__popcll(mE & ((1ull << lane) - 1ull))] = envSlot;
+          }
         }
       }
       if (STATS) tShade += __builtin_amdgcn_s_memtime() - tq1;
