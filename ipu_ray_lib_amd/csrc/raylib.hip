@@ -247,13 +247,6 @@ int g_wavesPerSimd = 5;          // MI_RAYLIB_WAVES=4: the 108-VGPR build of the
 
 constexpr uint32_t kLdsBudgetBytes = 160 * 1024 - 1024;     // 160 KiB per CU minus the static allocations
 
-// Workgroups of 256 threads that are resident at once with `perSimd` waves per SIMD (4 SIMDs per CU).
-uint32_t residentBlocks(const mi_scene& S, uint32_t perSimd) {
-  static int cus = 0;
-  if (!cus) { hipDeviceProp_t p; cus = (hipGetDeviceProperties(&p, S.device) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
-  return (uint32_t)cus * perSimd;
-}
-
 template <bool STATS>
 void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStream_t stream, int slot, const WaveExtras& ex = WaveExtras{}) {
   uint32_t* workCounter = S.d_workCounter + slot;
@@ -281,17 +274,17 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
   } else if (g_kernelChoice == 4) {
     // primitive tests pooled across the workgroup (LEAFQ): 17 KiB of LDS per workgroup
     const bool five = !STATS && g_wavesPerSimd == 5;
-    const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, ex.staticFetch ? residentBlocks(S, five ? 5 : 4) : 256 * 8);
+    const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, 256 * 8);
     if (five)
       hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, false, 5, true>), dim3(blocks), dim3(256), kLeafQBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, ex);
     else
       hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, false, 4, true>), dim3(blocks), dim3(256), kLeafQBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, ex);
   } else if (!STATS && g_wavesPerSimd == 5) {
     // 96-VGPR build: 5 waves per SIMD (+4.6 % on the box scene; 6 waves = 80 VGPRs spills in the hot loop: -9 %)
-    const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, ex.staticFetch ? residentBlocks(S, 5) : 256 * 8);   // fixed shares: resident workgroups only
+    const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, 256 * 8);
     hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, false, 5>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, ex);
   } else {
-    const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, ex.staticFetch ? residentBlocks(S, 4) : 256 * 8);
+    const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, 256 * 8);
     hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, false>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, ex);
   }
 }

@@ -74,8 +74,6 @@ struct WaveExtras {
   uint32_t* index = nullptr; uint32_t* count = nullptr;
   float azimuthRotation = 0.f;
   uint32_t fetchChunk = 0;       // work indices taken per global atomic (multiple of 64; 0 = 64)
-  uint32_t staticFetch = 0;      // 1: fixed equal share per wave, no global work counter
-  uint32_t fetchAt = 0;          // lanes that must wait for a pixel before the wave pays for a fetch (0 = 1: serve at once)
 };
 
 template <bool STATS, bool LDS_NODES, int BLOCK, bool TWO_RAYS, int WAVES_PER_SIMD = 4, bool LEAFQ = false>
@@ -106,16 +104,8 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
   }
 
   const uint32_t lane = threadIdx.x & 63;
-  const uint32_t fetchChunk = ex.fetchChunk ? ex.fetchChunk : 64u, fetchAt = ex.fetchAt ? ex.fetchAt : 1u;
+  const uint32_t fetchChunk = ex.fetchChunk ? ex.fetchChunk : 64u;
   uint32_t chunkNext = 0, chunkEnd = 0;          // wave-uniform: the local range of work indices not handed out yet
-  if (ex.staticFetch) {
-    // One sample per launch: every wave takes a fixed, equal share of the stream (whole 8x8 tiles) instead of
-    // pulling from the global counter - at ~60 paths per service the counter's same-address atomics serialise in L2.
-    const uint32_t waves = gridDim.x * (BLOCK / 64), wid = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-    const uint32_t per = ((n + waves * 64u - 1u) / (waves * 64u)) * 64u;
-    chunkNext = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(wid * per, n));
-    chunkEnd = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(chunkNext + per, n));
-  }
   const uint32_t tiledCount = tileStreamW ? (n / (8u * tileStreamW)) * (8u * tileStreamW) : 0u;
   const uint32_t numNodes = sc.numNodes;
   const uint32_t spp = ex.sampleCount ? ex.sampleCount : sc.samplesPerPixel;
@@ -286,15 +276,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
     for (;;) {
       const unsigned long long mF = __ballot(ph == PH_FETCH);
       if (!mF) break;
-      // Each service costs the wave a global round trip (counter, then the pixel record). With many samples per
-      // pixel that is rare and lanes are served at once; with one sample per launch every lane is back after a
-      // single path, so lanes wait until ex.fetchAt of them can be served together - unless nothing else can run.
-      if ((uint32_t)__popcll(mF) < fetchAt && __ballot(ph != PH_FETCH && ph != PH_DONE)) break;
       if (chunkNext >= chunkEnd) {
-        if (ex.staticFetch) {                       // this wave's fixed share is used up
-          if (ph == PH_FETCH) ph = PH_DONE;
-          break;
-        }
         const uint32_t firstF = (uint32_t)__ffsll((long long)mF) - 1u;
         uint32_t base = 0;
         if (lane == firstF) base = atomicAdd(workCounter, fetchChunk);
