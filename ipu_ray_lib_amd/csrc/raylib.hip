@@ -175,6 +175,9 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
           L.f[3 * k] = p.x; L.f[3 * k + 1] = p.y; L.f[3 * k + 2] = p.z;
         }
         L.type = LEAF_TRI | ((uint32_t)n.geom_id << 16); L.primID = n.prim_or_second_child; L.triBase = (uint32_t)base;
+        const f3 p0 = mk(L.f[0], L.f[1], L.f[2]), p1 = mk(L.f[3], L.f[4], L.f[5]), p2 = mk(L.f[6], L.f[7], L.f[8]);
+        const f3 fn = normalized(cross(p1 - p0, p2 - p0));                        // Mesh.hpp:112-114
+        L.n[0] = fn.x; L.n[1] = fn.y; L.n[2] = fn.z;
       } else if (r.type == 1) {
         const mi_sphere& s = d.spheres[r.index];
         L.f[0] = s.x; L.f[1] = s.y; L.f[2] = s.z; L.f[3] = s.radius; L.f[4] = s.radius * s.radius;   // Primitives.hpp:44

@@ -34,13 +34,17 @@ static_assert(sizeof(GNode) == 32, "GNode must stay 32 bytes");
 
 enum : uint32_t { LEAF_TRI = 0, LEAF_SPHERE = 1, LEAF_DISC = 2 };
 
-struct __attribute__((aligned(16))) GLeaf {       // 48 B pre-resolved primitive
+struct __attribute__((aligned(16))) GLeaf {       // 64 B pre-resolved primitive (the primitive test reads the first 48)
   float f[9];        // tri: p0,p1,p2 | sphere: cx,cy,cz,radius,radius2 | disc: nx,ny,nz,cx,cy,cz,r2
   uint32_t type;     // LEAF_* in bits 0..15, geomID in bits 16..31
   uint32_t primID;   // value reported in the hit record
   uint32_t triBase;  // tri: index of the triangle's first u16 in meshTris (for vertex normals)
+  float n[3];        // tri: the face normal normalise(cross(p1-p0, p2-p0)) (Mesh.hpp:112-114), evaluated once at
+                     // upload with the same binary32 operations the reference performs per hit (no contraction,
+                     // correctly rounded sqrt and divide on both sides), so SHADE just reads it
+  uint32_t pad;
 };
-static_assert(sizeof(GLeaf) == 48, "GLeaf must stay 48 bytes");
+static_assert(sizeof(GLeaf) == 64, "GLeaf must stay 64 bytes");
 __host__ __device__ __forceinline__ uint32_t leaf_kind(const GLeaf& L) { return L.type & 0xFFFFu; }
 __host__ __device__ __forceinline__ uint32_t leaf_geom(const GLeaf& L) { return L.type >> 16; }
 
@@ -230,10 +234,7 @@ __device__ __forceinline__ bool traverse(const DeviceScene& sc, f3 o, f3 d, floa
 __device__ __forceinline__ f3 hit_normal(const DeviceScene& sc, const Hit& h, f3 hp) {
   const GLeaf L = sc.leaves[h.leaf];
   if (leaf_kind(L) == LEAF_TRI) {
-    if (!sc.hasNormals) {
-      const f3 p0 = mk(L.f[0], L.f[1], L.f[2]), p1 = mk(L.f[3], L.f[4], L.f[5]), p2 = mk(L.f[6], L.f[7], L.f[8]);
-      return normalized(cross(p1 - p0, p2 - p0));
-    }
+    if (!sc.hasNormals) return mk(L.n[0], L.n[1], L.n[2]);
     const uint32_t fv = sc.geomFirstVertex[h.geomID];
     const mi_vec3 a = sc.meshNormals[fv + sc.meshTris[L.triBase]];
     const mi_vec3 b = sc.meshNormals[fv + sc.meshTris[L.triBase + 1]];

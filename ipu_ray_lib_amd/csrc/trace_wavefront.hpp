@@ -374,8 +374,9 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
           if (STATS) { itN++; lnN += stay; }
           if (ph == PH_NODE) {
             GNode nd;
+            // (uniform base + 32-bit byte offset: the load takes the scalar-base form, one shift instead of 64-bit address math)
             if (LDS_NODES && node < ldsNodeCount) nd = ldsNodes[node];
-            else nd = sc.nodes[node];
+            else nd = *reinterpret_cast<const GNode*>(reinterpret_cast<const char*>(sc.nodes) + (node << 5));
             if (STATS) cs.nodes++;
             // Box test (CompactBVH2Node.cpp:5-22, intersectRaySlab CompactBVH2Node.hpp:14-50).
             // Fast form: with finite origin and finite inverse direction no slab product can be NaN, and for
