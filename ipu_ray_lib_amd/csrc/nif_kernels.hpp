@@ -19,8 +19,8 @@
 // A-fragment order, so every weight load is a fully coalesced 1 KiB wave read served from L2. Both operand
 // streams are software-pipelined with inline-asm loads whose completion is counted by hand (hipcc sinks its own
 // loads to their first use at this register pressure): weights three k-steps deep in registers, activation
-// fragments two deep. Other shapes (8 waves x 64/96 rays, 4 waves x 64/128/192 rays) are kept selectable
-// (MI_RAYLIB_NIF_SHAPE) for widths whose LDS image does not fit and for the measurements in DESIGN.md.
+// fragments three deep. The 8-wave shapes (64 / 96 rays per row group) are kept selectable (MI_RAYLIB_NIF_SHAPE)
+// for widths whose LDS image does not fit and for the measurements in DESIGN.md.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -40,12 +40,10 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 
-// Two workgroup shapes of the same kernel (template parameters MT = 16-ray tiles per wave, RG = row groups):
-//   wide  : 4 waves x (TILES x 12) tiles, 192 rays per pass, one wave per SIMD with the accumulators in AGPRs.
-//           Every packed weight fragment is fetched ONCE per workgroup and amortised over 12 MFMAs, which
-//           takes the L1/TA weight stream (the limiter of the tall shape, profiles/r01_nif_pmc.csv) down 3x.
-//           Needs 192 x stride x 2 B of LDS: fits for hidden widths <= 320 with 48 features.
-//   tall  : 8 waves = 4 output-feature groups x 2 row halves, 128 rays per pass (any width up to 384).
+// Workgroup shapes of the same kernel (template parameters MT = 16-ray tiles per wave, RG = row groups):
+//   w6 (default) : 4 waves x 96 rays, two workgroups per CU; every packed weight fragment is fetched once per
+//                  workgroup and feeds 6 MFMAs. Needs 96 x stride x 2 B of LDS per workgroup.
+//   t6, t4       : 8 waves = 4 output-feature groups x 2 row groups of 96 / 64 rays (t4: any width up to 384).
 constexpr uint32_t kNifMaxLdsBytes = 160 * 1024 - 512;
 constexpr uint32_t kNifMaxLayers = 16;
 constexpr uint32_t kNifMaxTilesPerWave = 6;   // output-feature tiles (of 16) per wave: supports widths up to 384
@@ -261,19 +259,22 @@ __device__ __forceinline__ void nif_dense_layer(const NifParams& P, const NifLay
   auto step = [&](const h8 (&w)[TN], uint32_t ks, auto first) {
     // B fragment: X^T[k][ray] = X[ray = rowBase + 16m + (lane&15)][k = 32ks + 8(lane>>4) + j]
     const uint32_t a0 = xAddr0 + 64u * ks;
-    h8 xb[2];
+    h8 xb[3];                                   // three-deep ring: reads run two ray tiles ahead of the MFMAs
     readX(xb[0], a0);
+    if (MT > 1) readX(xb[1], a0 + mStep);
 #pragma unroll
     for (uint32_t m = 0; m < MT; ++m) {
-      if (m + 1 < MT) {
-        readX(xb[(m + 1) & 1], a0 + (m + 1) * mStep);
-        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(xb[m & 1]));
+      if (m + 2 < MT) {
+        readX(xb[(m + 2) % 3], a0 + (m + 2) * mStep);
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xb[m % 3]));
+      } else if (m + 1 < MT) {
+        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(xb[m % 3]));
       } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xb[m & 1]));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xb[m % 3]));
       }
 #pragma unroll
       for (uint32_t a = 0; a < TN; ++a)
-        acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[a], xb[m & 1], decltype(first)::value ? bv[a] : acc[a][m], 0, 0, 0);
+        acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[a], xb[m % 3], decltype(first)::value ? bv[a] : acc[a][m], 0, 0, 0);
     }
   };
   using TwoSets = std::integral_constant<int, 2 * TN>;
@@ -341,7 +342,7 @@ __device__ __forceinline__ void nif_dense_layer(const NifParams& P, const NifLay
 // rays[idx[r]].rgb as throughput * (b,g,r)->(r,g,b) (PostProcessEscapedRays).
 // TILES = most output-feature tiles any layer gives a wave; layers with fewer run their own instantiation.
 template <uint32_t TILES, uint32_t MT, uint32_t RG>
-__global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : (MT == 4 && RG == 1) ? 3 : 1) nif_mlp_kernel(NifParams P, const h8* __restrict__ weights, const float* __restrict__ bias,
+__global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : 1) nif_mlp_kernel(NifParams P, const h8* __restrict__ weights, const float* __restrict__ bias,
                                                       const float* __restrict__ u, const float* __restrict__ v,
                                                       const uint32_t* __restrict__ idx, const uint32_t* __restrict__ countPtr,
                                                       uint32_t numRows, float* __restrict__ bgrOut, mi_trace_result* rays, bool scatter) {
@@ -400,11 +401,12 @@ inline void nif_launch_mlp(const NifDevice& nif, const float* u, const float* v,
   if (numRows == 0) return;
   uint32_t maxTiles = 1;
   for (uint32_t l = 0; l < nif.p.numLayers; ++l) maxTiles = std::max(maxTiles, nif.p.layers[l].nTiles / 4);
-  // shape: MT ray tiles per wave x RG row groups (see the table at the top); MI_RAYLIB_NIF_SHAPE=t4|t6|w4|w6|w8|w12 overrides (default w6)
+  // shape: MT ray tiles per wave x RG row groups. MI_RAYLIB_NIF_SHAPE=w6|t6|t4 overrides the default (w6).
+  // (4 waves x 64 / 128 / 192 rays were measured too - DESIGN.md §6 - and are not kept: at their register
+  // pressure hipcc spills around the hand-counted asm loads, which the .s audit in tests/ flags.)
   const char* shapeEnv = getenv("MI_RAYLIB_NIF_SHAPE");
   uint32_t mt = 6, rg = 1;
-  if (shapeEnv) { rg = shapeEnv[0] == 't' ? 2 : 1; mt = (uint32_t)atoi(shapeEnv + 1); }
-  if (!(rg == 2 && (mt == 4 || mt == 6)) && !(rg == 1 && (mt == 4 || mt == 6 || mt == 8 || mt == 12))) { mt = 6; rg = 1; }
+  if (shapeEnv && shapeEnv[0] == 't') { rg = 2; mt = (shapeEnv[1] == '6') ? 6 : 4; }
   if (!(mt == 4 && rg == 2) && ((size_t)16 * mt * rg * nif.p.stride * sizeof(_Float16) > kNifMaxLdsBytes || maxTiles > 5)) { mt = 4; rg = 2; }
   auto launch = [&](auto kern, uint32_t rowsPerPass, uint32_t threads) {
     const size_t lds = (size_t)rowsPerPass * nif.p.stride * sizeof(_Float16);
@@ -413,21 +415,12 @@ inline void nif_launch_mlp(const NifDevice& nif, const float* u, const float* v,
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNifMaxLdsBytes);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, nif.p, nif.d_weights, nif.d_bias, u, v, idx, countPtr, numRows, bgrOut, rays, scatter);
   };
-  if (mt == 6 && rg == 2) {
-    if (maxTiles <= 2) launch(nif_mlp_kernel<2, 6, 2>, 192, 512);
-    else launch(nif_mlp_kernel<5, 6, 2>, 192, 512);
-  } else if (mt == 12) {
-    if (maxTiles <= 2) launch(nif_mlp_kernel<2, 12, 1>, 192, 256);
-    else launch(nif_mlp_kernel<5, 12, 1>, 192, 256);
-  } else if (mt == 8) {
-    if (maxTiles <= 2) launch(nif_mlp_kernel<2, 8, 1>, 128, 256);
-    else launch(nif_mlp_kernel<5, 8, 1>, 128, 256);
-  } else if (mt == 6) {
+  if (mt == 6 && rg == 1) {
     if (maxTiles <= 2) launch(nif_mlp_kernel<2, 6, 1>, 96, 256);
     else launch(nif_mlp_kernel<5, 6, 1>, 96, 256);
-  } else if (mt == 4 && rg == 1) {
-    if (maxTiles <= 2) launch(nif_mlp_kernel<2, 4, 1>, 64, 256);
-    else launch(nif_mlp_kernel<5, 4, 1>, 64, 256);
+  } else if (mt == 6) {
+    if (maxTiles <= 2) launch(nif_mlp_kernel<2, 6, 2>, 192, 512);
+    else launch(nif_mlp_kernel<5, 6, 2>, 192, 512);
   } else {
     if (maxTiles <= 2) launch(nif_mlp_kernel<2, 4, 2>, 128, 512);
     else if (maxTiles <= 4) launch(nif_mlp_kernel<4, 4, 2>, 128, 512);
