@@ -248,7 +248,7 @@ WaveTune g_tune = {5, 8, 12, 32, 2, 16};
 int g_kernelChoice = 1;           // 0 = nested-loop kernel, 1 = wavefront (global nodes), 2 = wavefront + LDS-staged nodes
 int g_wavesPerSimd = 5;          // MI_RAYLIB_WAVES=4: the 108-VGPR build of the default kernel (4 waves per SIMD)
 
-constexpr uint32_t kLdsBudgetBytes = 160 * 1024 - 1024;     // 160 KiB per CU minus the static allocations
+constexpr uint32_t kLdsBudgetBytes = 160 * 1024 - 1024 - 8 * 1024 * 4;     // 160 KiB per CU minus the static allocations (sin table, 8 cold-state words x 1024 threads)
 
 template <bool STATS>
 void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStream_t stream, int slot, const WaveExtras& ex = WaveExtras{}) {

@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
   uint32_t pix = 0, sample = 0, bounce = 0, node = 0, pendLeaf = 0;
   float prow = 0.f, pcol = 0.f;
   Rng rng; rng.s0 = rng.s1 = 0;
-  f3 rgb = mk(0, 0, 0), color = mk(0, 0, 0), tp = mk(1, 1, 1);
+  f3 color = mk(0, 0, 0), tp = mk(1, 1, 1);
   f3 o = mk(0, 0, 0), d = mk(0, 0, -1), nrm = mk(0, 0, 1), inv = mk(0, 0, 0);
   Shear sh; sh.kz = 2; sh.sx = sh.sy = 0.f; sh.sz = 1.f;
   Hit hit; hit.t = kInf; hit.leaf = 0xFFFFFFFFu; hit.geomID = 0xFFFFu; hit.b0 = hit.b1 = hit.b2 = 0.f;
@@ -123,6 +123,14 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
   uint32_t phB = (uint32_t)PH_DONE;   // TWO_RAYS: phase of the ray parked in this lane's LDS slot (re-read at every vote)
   bool exactSlab = false;
   float oTmax = kInf;
+  // Cold per-lane state lives in LDS (6 dwords per lane, [word][thread] so a wave's accesses are conflict-free): the
+  // pixel's stream index, its (row, col) and its running rgb sum are touched once per path or per pixel, and holding
+  // them in VGPRs made the 96-register build spill inside the traversal loop. (TWO_RAYS keeps them in its parked
+  // record / in memory instead.)
+  __shared__ uint32_t coldLds[TWO_RAYS ? 1 : 8 * BLOCK];   // + the last hit's leaf and distance (words 6, 7)
+  auto coldU = [&](uint32_t w) -> uint32_t& { return coldLds[w * BLOCK + threadIdx.x]; };
+  auto coldF = [&](uint32_t w) -> float& { return reinterpret_cast<float*>(coldLds)[w * BLOCK + threadIdx.x]; };
+  auto getPix = [&]() -> uint32_t { return TWO_RAYS ? pix : coldU(0); };
   CastStats cs = {0, 0};
   uint32_t casts = 0, paths = 0;
   // STATS only: per-wave phase executions and the lanes that were active in them (wave-uniform values)
@@ -301,7 +309,10 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
           pix = entry;
           const mi_trace_result* res = rays + entry;
           prow = res->u; pcol = res->v;
-          if (!TWO_RAYS) rgb = mk(res->rgb.x, res->rgb.y, res->rgb.z);   // TWO_RAYS accumulates rgb in memory
+          if (!TWO_RAYS) {                                                // TWO_RAYS accumulates rgb in memory
+            coldU(0) = entry; coldF(1) = prow; coldF(2) = pcol;
+            coldF(3) = res->rgb.x; coldF(4) = res->rgb.y; coldF(5) = res->rgb.z;
+          }
           if (ex.rngState && !ex.seedNow) rng = ex.rngState[entry];
           else rng_seed_pixel(rng, sc.rngSeed, prow, pcol);
           sample = 0;
@@ -470,7 +481,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
         if (hit.leaf != 0xFFFFFFFFu) {
           const GLeaf L = sc.leaves[hit.leaf];
           hit.geomID = leaf_geom(L);
-          oLeaf = hit.leaf; oTmax = hit.t;
+          if (TWO_RAYS) { oLeaf = hit.leaf; oTmax = hit.t; } else { coldU(6) = hit.leaf; coldF(7) = hit.t; }
           o = o + d * hit.t;                                          // updateHit, Render.hpp:15-23
           nrm = hit_normal(sc, hit, o);
           const mi_material mat = sc.materials[sc.matIDs[hit.geomID]];
@@ -491,12 +502,12 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
             d = nd2;
             if (refracted) tp = tp * albedo;
           } else {
-            if (TWO_RAYS) { mi_trace_result* res = rays + pix; const float qn = __builtin_nanf(""); res->rgb = {res->rgb.x * qn, res->rgb.y * qn, res->rgb.z * qn}; }
-            else rgb = rgb * __builtin_nanf("");
+            if (TWO_RAYS) { mi_trace_result* res = rays + getPix(); const float qn = __builtin_nanf(""); res->rgb = {res->rgb.x * qn, res->rgb.y * qn, res->rgb.z * qn}; }
+            else { const float qn = __builtin_nanf(""); coldF(3) = coldF(3) * qn; coldF(4) = coldF(4) * qn; coldF(5) = coldF(5) * qn; }
             oFlags |= MI_FLAG_ERROR;
           }
         } else {
-          oTmax = kInf;
+          if (TWO_RAYS) oTmax = kInf; else coldF(7) = kInf;
           oFlags |= MI_FLAG_ESCAPED;
           terminated = true;
         }
@@ -507,32 +518,34 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
         bounce++;
         if (bounce >= sc.maxPathLength) terminated = true;
         if (terminated) {
-          mi_trace_result* res = rays + pix;
+          const uint32_t pixNow = getPix();
+          mi_trace_result* res = rays + pixNow;
           if (ex.slotColor) {
-            const size_t q = (size_t)sample * n + pix;
+            const size_t q = (size_t)sample * n + pixNow;
             ex.slotColor[3 * q] = color.x; ex.slotColor[3 * q + 1] = color.y; ex.slotColor[3 * q + 2] = color.z;
             envRay = (oFlags & MI_FLAG_ESCAPED) != 0;
             envSlot = (uint32_t)q;
             if (!envRay) ex.u[q] = -1.f;
           } else if (TWO_RAYS) { const mi_vec3 acc = res->rgb; res->rgb = {acc.x + color.x, acc.y + color.y, acc.z + color.z}; }
-          else rgb = rgb + color;
+          else { coldF(3) = coldF(3) + color.x; coldF(4) = coldF(4) + color.y; coldF(5) = coldF(5) + color.z; }
           ++paths;
           ++sample;
           if (sample < spp) ph = PH_GEN;
           else {
             // pixel complete: rgb sum + the LAST sample's hit record
-            if (!TWO_RAYS && !ex.slotColor) res->rgb = {rgb.x, rgb.y, rgb.z};
+            if (!TWO_RAYS && !ex.slotColor) res->rgb = {coldF(3), coldF(4), coldF(5)};
             uint32_t oPrim = MI_INVALID_PRIM, oGeom = MI_INVALID_GEOM;
-            if (oLeaf != 0xFFFFFFFFu) { const GLeaf LL = sc.leaves[oLeaf]; oPrim = LL.primID; oGeom = leaf_geom(LL); }
+            const uint32_t lastLeaf = TWO_RAYS ? oLeaf : coldU(6);
+            if (lastLeaf != 0xFFFFFFFFu) { const GLeaf LL = sc.leaves[lastLeaf]; oPrim = LL.primID; oGeom = leaf_geom(LL); }
             mi_hit_record hr;
             hr.r.origin = {o.x, o.y, o.z}; hr.r.t_min = 0.f;
-            hr.r.direction = {d.x, d.y, d.z}; hr.r.t_max = oTmax;
+            hr.r.direction = {d.x, d.y, d.z}; hr.r.t_max = TWO_RAYS ? oTmax : coldF(7);
             hr.prim_id = oPrim;
             hr.normal = {nrm.x, nrm.y, nrm.z};
             hr.throughput = {tp.x, tp.y, tp.z};
             hr.geom_id = (uint16_t)oGeom; hr.flags = (uint16_t)oFlags;
             res->h = hr;
-            if (ex.rngState) ex.rngState[pix] = rng;
+            if (ex.rngState) ex.rngState[pixNow] = rng;
             ph = PH_FETCH;
           }
         } else {
@@ -577,13 +590,15 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
       const unsigned long long tq2 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
       if (ph == PH_GEN) {
         if (TWO_RAYS) { prow = rays[pix].u; pcol = rays[pix].v; }     // not part of the parked state
+        else { prow = coldF(1); pcol = coldF(2); }
         float g0, g1;
         rng_gauss2(rng, sinTbl, g0, g1);
         const float jr = prow + sc.antiAliasScale * g0, jc = pcol + sc.antiAliasScale * g1;
         d = pixel_to_ray_dir(jc, jr, sc.imageWidth, sc.imageHeight, sc.tanTheta);
         o = mk(0.f, 0.f, 0.f);
         nrm = mk(0.f, 0.f, 1.f);                         // HitRecord ctor, geometry.hpp:236-242
-        oLeaf = 0xFFFFFFFFu; oFlags = 0; oTmax = kInf;
+        if (TWO_RAYS) { oLeaf = 0xFFFFFFFFu; oTmax = kInf; } else { coldU(6) = 0xFFFFFFFFu; coldF(7) = kInf; }
+        oFlags = 0;
         tp = mk(1.f, 1.f, 1.f);
         color = mk(0.f, 0.f, 0.f);
         bounce = 0;
