@@ -248,7 +248,7 @@ WaveTune g_tune = {5, 8, 12, 32, 2, 16};
 int g_kernelChoice = 1;           // 0 = nested-loop kernel, 1 = wavefront (global nodes), 2 = wavefront + LDS-staged nodes
 int g_wavesPerSimd = 5;          // MI_RAYLIB_WAVES=4: the 108-VGPR build of the default kernel (4 waves per SIMD)
 
-constexpr uint32_t kLdsBudgetBytes = 160 * 1024 - 1024 - 8 * 1024 * 4;     // 160 KiB per CU minus the static allocations (sin table, 8 cold-state words x 1024 threads)
+constexpr uint32_t kLdsBudgetBytes = 160 * 1024 - 1024 - 23 * 1024 * 4;     // 160 KiB per CU minus the static allocations (sin table, 23 cold-state words x 1024 threads)
 
 template <bool STATS>
 void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStream_t stream, int slot, const WaveExtras& ex = WaveExtras{}) {
@@ -283,7 +283,7 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
     else
       hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, false, 4, true>), dim3(blocks), dim3(256), kLeafQBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, ex);
   } else if (!STATS && g_wavesPerSimd == 5) {
-    // 96-VGPR build: 5 waves per SIMD (+4.6 % on the box scene; 6 waves = 80 VGPRs spills in the hot loop: -9 %)
+    // 96-VGPR build: 5 waves per SIMD (+4.6 % on the box scene; 6 waves = 80 VGPRs: -15 %, its spills land in LEAF/SHADE)
     const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, 256 * 8);
     hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, false, 5>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, ex);
   } else {

@@ -127,10 +127,26 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
   // pixel's stream index, its (row, col) and its running rgb sum are touched once per path or per pixel, and holding
   // them in VGPRs made the 96-register build spill inside the traversal loop. (TWO_RAYS keeps them in its parked
   // record / in memory instead.)
-  __shared__ uint32_t coldLds[TWO_RAYS ? 1 : 8 * BLOCK];   // + the last hit's leaf and distance (words 6, 7)
+  __shared__ uint32_t coldLds[TWO_RAYS ? 1 : 23 * BLOCK];   // + the last hit's leaf and distance (6, 7) + the path state (8..22)
   auto coldU = [&](uint32_t w) -> uint32_t& { return coldLds[w * BLOCK + threadIdx.x]; };
   auto coldF = [&](uint32_t w) -> float& { return reinterpret_cast<float*>(coldLds)[w * BLOCK + threadIdx.x]; };
   auto getPix = [&]() -> uint32_t { return TWO_RAYS ? pix : coldU(0); };
+  // Path state that only SHADE / GEN / FETCH touch - the RNG, radiance, throughput, normal, bounce and sample
+  // counters - is loaded at the top of those phases and stored at their end, so it holds no registers while the
+  // wave traverses (words 8..22).
+  auto pathLoad = [&]() {
+    if (TWO_RAYS) return;
+    rng.s0 = (uint64_t)coldU(8) | ((uint64_t)coldU(9) << 32); rng.s1 = (uint64_t)coldU(10) | ((uint64_t)coldU(11) << 32);
+    color = mk(coldF(12), coldF(13), coldF(14)); tp = mk(coldF(15), coldF(16), coldF(17)); nrm = mk(coldF(18), coldF(19), coldF(20));
+    bounce = coldU(21); sample = coldU(22);
+  };
+  auto pathStore = [&]() {
+    if (TWO_RAYS) return;
+    coldU(8) = (uint32_t)rng.s0; coldU(9) = (uint32_t)(rng.s0 >> 32); coldU(10) = (uint32_t)rng.s1; coldU(11) = (uint32_t)(rng.s1 >> 32);
+    coldF(12) = color.x; coldF(13) = color.y; coldF(14) = color.z; coldF(15) = tp.x; coldF(16) = tp.y; coldF(17) = tp.z;
+    coldF(18) = nrm.x; coldF(19) = nrm.y; coldF(20) = nrm.z;
+    coldU(21) = bounce; coldU(22) = sample;
+  };
   CastStats cs = {0, 0};
   uint32_t casts = 0, paths = 0;
   // STATS only: per-wave phase executions and the lanes that were active in them (wave-uniform values)
@@ -316,6 +332,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
           if (ex.rngState && !ex.seedNow) rng = ex.rngState[entry];
           else rng_seed_pixel(rng, sc.rngSeed, prow, pcol);
           sample = 0;
+          pathStore();                 // (GEN initialises the rest)
           ph = PH_GEN;
         } else {
           ph = PH_DONE;
@@ -477,6 +494,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
       bool envRay = false;          // this lane's path ended in this SHADE step by escaping (slot mode)
       uint32_t envSlot = 0;
       if (ph == PH_SHADE) {
+        pathLoad();
         bool terminated = false;
         if (hit.leaf != 0xFFFFFFFFu) {
           const GLeaf L = sc.leaves[hit.leaf];
@@ -559,6 +577,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
           ++casts;
           ph = (numNodes > 0) ? PH_NODE : PH_SHADE;
         }
+        pathStore();
       }
       if (ex.slotColor) {
         const unsigned long long mE = __ballot(envRay);
@@ -589,6 +608,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
       if (STATS) { itG++; lnG += cG; }
       const unsigned long long tq2 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
       if (ph == PH_GEN) {
+        pathLoad();
         if (TWO_RAYS) { prow = rays[pix].u; pcol = rays[pix].v; }     // not part of the parked state
         else { prow = coldF(1); pcol = coldF(2); }
         float g0, g1;
@@ -610,6 +630,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
         node = 0;
         ++casts;
         ph = (numNodes > 0) ? PH_NODE : PH_SHADE;
+        pathStore();
       }
       if (STATS) tGen += __builtin_amdgcn_s_memtime() - tq2;
     }
