@@ -8,6 +8,7 @@
 """
 import ctypes as C
 import re
+import subprocess
 from pathlib import Path
 
 import numpy as np
@@ -207,3 +208,12 @@ def test_product_does_not_reach_into_the_oracle():
         if p.suffix in {".py", ".h", ".hpp", ".hip", ".cpp"}:
             txt = p.read_text()
             assert "ray_oracle" not in txt and "oracle_lib" not in txt and "libray_oracle" not in txt, p
+
+
+def test_headers_are_plain_c99(tmp_path):
+    """The drop-in boundary is a C ABI: both public headers must compile as strict C99 on their own."""
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "mi_raylib.h"\n#include "mi_scene_host.h"\nint main(void) { return (int)sizeof(mi_trace_result) - 84; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", str(ROOT / "include"), "-fsyntax-only", str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
