@@ -87,6 +87,7 @@ struct mi_scene {
   // scratch for the per-sample NIF loop
   Rng* d_rng = nullptr; float* d_u = nullptr; float* d_v = nullptr; float* d_bgr = nullptr; size_t scratchRays = 0;
   float* d_slotColor = nullptr; float* d_slotTp = nullptr;   // NIF renders: per-(sample, pixel) slots of one launch
+  uint32_t scratchSamples = 0;                                // samples per launch the slot buffers are sized for
 
   ~mi_scene() {
     (void)hipSetDevice(device);
@@ -221,10 +222,15 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
   S.keep(S.d_workCounter);
 }
 
-uint32_t kNifSamplesPerLaunch = 16;  // slots per pixel per launch in NIF renders (44 B each); MI_RAYLIB_NIF_SPL overrides (1..64)
+  // slots per pixel per launch in NIF renders (44 B each); MI_RAYLIB_NIF_SPL overrides (1..64)
 
 void ensureScratch(mi_scene& S, size_t n) {
-  if (const char* e = getenv("MI_RAYLIB_NIF_SPL")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v <= 64 && v != kNifSamplesPerLaunch) { kNifSamplesPerLaunch = v; S.scratchRays = 0; } }
+  {
+    const char* e = getenv("MI_RAYLIB_NIF_SPL");
+    uint32_t v = e ? (uint32_t)atoi(e) : 16u;
+    if (v < 1 || v > 64) v = 16u;
+    if (v != S.scratchSamples) { S.scratchSamples = v; S.scratchRays = 0; }     // slot buffers are sized for n x v
+  }
   if (S.scratchRays >= n) return;
   if (S.d_rng) (void)hipFree(S.d_rng);
   if (S.d_u) (void)hipFree(S.d_u);
@@ -233,7 +239,7 @@ void ensureScratch(mi_scene& S, size_t n) {
   if (S.d_slotColor) (void)hipFree(S.d_slotColor);
   if (S.d_slotTp) (void)hipFree(S.d_slotTp);
   S.d_rng = nullptr; S.d_u = S.d_v = S.d_bgr = S.d_slotColor = S.d_slotTp = nullptr; S.scratchRays = 0;
-  const size_t slots = n * kNifSamplesPerLaunch;
+  const size_t slots = n * S.scratchSamples;
   HIP_CHECK(hipMalloc(&S.d_rng, n * sizeof(Rng)));
   HIP_CHECK(hipMalloc(&S.d_u, slots * sizeof(float)));
   HIP_CHECK(hipMalloc(&S.d_v, slots * sizeof(float)));
@@ -318,10 +324,10 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
       if (wave) {
         // persistent phase-scheduled kernel, several samples per launch; every path leaves a slot (WaveExtras), the
         // MLP runs on the compacted escaped slots, and a per-pixel pass adds everything in the reference's order
-        if ((uint64_t)cnt * kNifSamplesPerLaunch > 0xFFFFFFFFull) throw ArgError("mi_render: ray batch too large for a NIF render (cut it with mi_scene_set_ray_batch)");
-        S.nif.ensureIndex((size_t)cnt * kNifSamplesPerLaunch);
-        for (uint32_t s0 = 0; s0 < S.ds.samplesPerPixel; s0 += kNifSamplesPerLaunch) {
-          const uint32_t sc = std::min<uint32_t>(kNifSamplesPerLaunch, S.ds.samplesPerPixel - s0);
+        if ((uint64_t)cnt * S.scratchSamples > 0xFFFFFFFFull) throw ArgError("mi_render: ray batch too large for a NIF render (cut it with mi_scene_set_ray_batch)");
+        S.nif.ensureIndex((size_t)cnt * S.scratchSamples);
+        for (uint32_t s0 = 0; s0 < S.ds.samplesPerPixel; s0 += S.scratchSamples) {
+          const uint32_t sc = std::min<uint32_t>(S.scratchSamples, S.ds.samplesPerPixel - s0);
           HIP_CHECK(hipMemsetAsync(S.nif.d_count, 0, sizeof(uint32_t), stream));
           WaveExtras ex;
           ex.rngState = S.d_rng; ex.seedNow = (s0 == 0) ? 1u : 0u; ex.sampleCount = sc;
