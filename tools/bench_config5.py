@@ -26,7 +26,7 @@ dev.run_device(t.data_ptr(), n, irl.MODE_PATH_TRACE, st); torch.cuda.synchronize
 el = time.perf_counter() - t0
 c = dev.counters()
 out = t.cpu().numpy().view(irl.TRACE_RESULT).reshape(-1)
-esc = float((out["h"]["flags"] & 1).mean())
+esc = float(((out["h"]["flags"] & irl.FLAG_ESCAPED) != 0).mean())
 print(json.dumps({"workload": f"monkey + NIF {size}x{size} x {spp} spp", "ms_per_sample": el / spp * 1e3, "paths_per_s": c["paths"] / el,
                   "casts_per_path": c["casts"] / max(c["paths"], 1), "escaped_fraction_last_sample": esc, "rgb_sum": float(out["rgb"]["x"].sum())}))
 import os
