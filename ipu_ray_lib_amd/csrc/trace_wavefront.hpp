@@ -54,7 +54,7 @@ constexpr uint32_t kLeafQEmpty = 0xFFFFFFFFu;
 //   shadeAt, genAt   top-level vote: SHADE/GEN run when their weighted population exceeds (cN+cL)*4
 //   burst    at most this many NODE/LEAF steps before the wave re-votes
 //   keep8    ... or earlier, once fewer than keep8/8 of the lanes that started the burst still traverse
-struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, tradeAt, qPush = 4, qServe = 48; };
+struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, tradeAt, qPush = 4, qServe = 48, dbl = 12, maxExtra = 2; };
 
 // Per-launch extras for renders with the NIF environment. The reference traces ONE sample, evaluates the
 // environment for the rays that escaped, adds it, and repeats (src/IpuScene.cpp:571-583). One sample per launch
@@ -395,47 +395,60 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
       // lanes only change rays in SHADE/GEN (or in a trade), so "some lane needs the literal box test" is a
       // per-burst fact
       bool anyExact = __ballot(exactSlab) != 0ull;
+      auto nodeStep = [&]() {
+        if (ph == PH_NODE) {
+          GNode nd;
+          // (uniform base + 32-bit byte offset: the load takes the scalar-base form, one shift instead of 64-bit address math)
+          if (LDS_NODES && node < ldsNodeCount) nd = ldsNodes[node];
+          else nd = *reinterpret_cast<const GNode*>(reinterpret_cast<const char*>(sc.nodes) + (node << 5));
+          if (STATS) cs.nodes++;
+          // Box test (CompactBVH2Node.cpp:5-22, intersectRaySlab CompactBVH2Node.hpp:14-50).
+          // Fast form: with finite origin and finite inverse direction no slab product can be NaN, and for
+          // non-NaN values the reference's ordered compare/selects ARE min/max: swap(tmin,tmax) = (min,max),
+          // "t0 = tmin > t0 ? tmin : t0" = max, "t1 = tmax < t1 ? tmax : t1" = min, in any axis order; the
+          // sign of a zero never reaches the result (only t0 > t1 is used). Lanes whose ray has a zero /
+          // denormal direction component or a non-finite origin (exactSlab) redo the test with the
+          // reference's literal compare/select sequence below, so NaN cases stay bit-identical too.
+          // The far side is scaled ONCE: x -> fl(x * kSlabScale) is monotone non-decreasing, so
+          // min(fl(bx*s), fl(by*s), fl(bz*s)) == fl(min(bx, by, bz) * s) bit for bit (no NaNs on this path).
+          const float ax = (nd.minx - o.x) * inv.x, bx = (nd.maxx - o.x) * inv.x;
+          const float ay = (nd.miny - o.y) * inv.y, by = (nd.maxy - o.y) * inv.y;
+          const float az = (nd.minz - o.z) * inv.z, bz = (nd.maxz - o.z) * inv.z;
+          float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
+          float t1 = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * kSlabScale, hit.t);
+          if (TWO_RAYS ? (__ballot(exactSlab) != 0ull) : anyExact) {
+            if (exactSlab) {
+              t0 = 0.f; t1 = hit.t;
+              { float tmin = ax, tmax = bx; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
+              { float tmin = ay, tmax = by; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
+              { float tmin = az, tmax = bz; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
+            }
+          }
+          const bool boxHit = !(t0 > t1);
+          const bool isLeaf = nd.geomID != 0xFFFFu;
+          if (boxHit && isLeaf) {
+            pendLeaf = nd.link;
+            ph = PH_LEAF;
+          } else {
+            node = (boxHit || isLeaf) ? node + 1 : nd.link;
+            if (node >= numNodes) ph = PH_SHADE;
+          }
+        }
+      };
       for (;;) {
         const uint32_t stay = cN;
         if (LEAFQ ? (cN > 0) : (cN * 4u >= cL * tune.leafAt && cN > 0)) {
-          // NODE: one box test per lane
+          // NODE: one box test per lane. With many lanes in the walk two box tests run back to back before the wave
+          // votes again (tune.dbl): a vote costs a ballot-popcount-branch chain whose latency the second test hides;
+          // lanes that reached a leaf in the first simply sit the second out.
           if (STATS) { itN++; lnN += stay; }
-          if (ph == PH_NODE) {
-            GNode nd;
-            // (uniform base + 32-bit byte offset: the load takes the scalar-base form, one shift instead of 64-bit address math)
-            if (LDS_NODES && node < ldsNodeCount) nd = ldsNodes[node];
-            else nd = *reinterpret_cast<const GNode*>(reinterpret_cast<const char*>(sc.nodes) + (node << 5));
-            if (STATS) cs.nodes++;
-            // Box test (CompactBVH2Node.cpp:5-22, intersectRaySlab CompactBVH2Node.hpp:14-50).
-            // Fast form: with finite origin and finite inverse direction no slab product can be NaN, and for
-            // non-NaN values the reference's ordered compare/selects ARE min/max: swap(tmin,tmax) = (min,max),
-            // "t0 = tmin > t0 ? tmin : t0" = max, "t1 = tmax < t1 ? tmax : t1" = min, in any axis order; the
-            // sign of a zero never reaches the result (only t0 > t1 is used). Lanes whose ray has a zero /
-            // denormal direction component or a non-finite origin (exactSlab) redo the test with the
-            // reference's literal compare/select sequence below, so NaN cases stay bit-identical too.
-            // The far side is scaled ONCE: x -> fl(x * kSlabScale) is monotone non-decreasing, so
-            // min(fl(bx*s), fl(by*s), fl(bz*s)) == fl(min(bx, by, bz) * s) bit for bit (no NaNs on this path).
-            const float ax = (nd.minx - o.x) * inv.x, bx = (nd.maxx - o.x) * inv.x;
-            const float ay = (nd.miny - o.y) * inv.y, by = (nd.maxy - o.y) * inv.y;
-            const float az = (nd.minz - o.z) * inv.z, bz = (nd.maxz - o.z) * inv.z;
-            float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
-            float t1 = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * kSlabScale, hit.t);
-            if (TWO_RAYS ? (__ballot(exactSlab) != 0ull) : anyExact) {
-              if (exactSlab) {
-                t0 = 0.f; t1 = hit.t;
-                { float tmin = ax, tmax = bx; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
-                { float tmin = ay, tmax = by; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
-                { float tmin = az, tmax = bz; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
-              }
-            }
-            const bool boxHit = !(t0 > t1);
-            const bool isLeaf = nd.geomID != 0xFFFFu;
-            if (boxHit && isLeaf) {
-              pendLeaf = nd.link;
-              ph = PH_LEAF;
-            } else {
-              node = (boxHit || isLeaf) ? node + 1 : nd.link;
-              if (node >= numNodes) ph = PH_SHADE;
+          nodeStep();
+          if (!LEAFQ && !TWO_RAYS) {
+            const uint32_t extra = min(stay / tune.dbl, tune.maxExtra);
+            for (uint32_t e = 0; e < extra; ++e) {
+              if (STATS) { itN++; lnN += (uint32_t)__popcll(__ballot(ph == PH_NODE)); }
+              nodeStep();
+              ++steps;
             }
           }
         } else if (LEAFQ) {
