@@ -54,7 +54,7 @@ constexpr uint32_t kLeafQEmpty = 0xFFFFFFFFu;
 //   shadeAt, genAt   top-level vote: SHADE/GEN run when their weighted population exceeds (cN+cL)*4
 //   burst    at most this many NODE/LEAF steps before the wave re-votes
 //   keep8    ... or earlier, once fewer than keep8/8 of the lanes that started the burst still traverse
-struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, tradeAt, qPush = 4, qServe = 48, dbl = 12, maxExtra = 2; };
+struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, tradeAt, qPush = 4, qServe = 48, dbl = 12, maxExtra = 2, leafThenNode = 1; };
 
 // Per-launch extras for renders with the NIF environment. The reference traces ONE sample, evaluates the
 // environment for the rays that escaped, adds it, and repeats (src/IpuScene.cpp:571-583). One sample per launch
@@ -475,6 +475,13 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
             if (cand && t > 0.f && t < hit.t) { hit.t = t; hit.leaf = pendLeaf; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2; }
             node = node + 1;
             ph = (node >= numNodes) ? PH_SHADE : PH_NODE;
+          }
+          // every lane that waited for a primitive test is walking again: the next vote would pick NODE anyway,
+          // so a box test follows at once (tune.leafThenNode) and the vote after it sees its outcome
+          if (!TWO_RAYS && tune.leafThenNode) {
+            if (STATS) { itN++; lnN += (uint32_t)__popcll(__ballot(ph == PH_NODE)); }
+            nodeStep();
+            ++steps;
           }
         }
         cN = (uint32_t)__popcll(__ballot(ph == PH_NODE));
