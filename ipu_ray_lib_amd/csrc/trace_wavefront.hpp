@@ -54,7 +54,7 @@ constexpr uint32_t kLeafQEmpty = 0xFFFFFFFFu;
 //   shadeAt, genAt   top-level vote: SHADE/GEN run when their weighted population exceeds (cN+cL)*4
 //   burst    at most this many NODE/LEAF steps before the wave re-votes
 //   keep8    ... or earlier, once fewer than keep8/8 of the lanes that started the burst still traverse
-struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, tradeAt, qPush = 4, qServe = 48, dbl = 12, maxExtra = 2, leafThenNode = 1; };
+struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, tradeAt, qPush = 4, qServe = 48, dbl = 6, maxExtra = 5, leafThenNode = 1; };
 
 // Per-launch extras for renders with the NIF environment. The reference traces ONE sample, evaluates the
 // environment for the rays that escaped, adds it, and repeats (src/IpuScene.cpp:571-583). One sample per launch
@@ -445,11 +445,11 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
           nodeStep();
           if (!LEAFQ && !TWO_RAYS) {
             const uint32_t extra = min(stay / tune.dbl, tune.maxExtra);
-            for (uint32_t e = 0; e < extra; ++e) {
-              if (STATS) { itN++; lnN += (uint32_t)__popcll(__ballot(ph == PH_NODE)); }
-              nodeStep();
-              ++steps;
-            }
+            // (spelled out rather than looped: straight-line code lets the next test's node load issue under the
+            //  previous test's arithmetic)
+#define MI_EXTRA_NODE_STEP(k) if (extra >= k) { if (STATS) { itN++; lnN += (uint32_t)__popcll(__ballot(ph == PH_NODE)); } nodeStep(); ++steps; }
+            MI_EXTRA_NODE_STEP(1) MI_EXTRA_NODE_STEP(2) MI_EXTRA_NODE_STEP(3) MI_EXTRA_NODE_STEP(4) MI_EXTRA_NODE_STEP(5)
+#undef MI_EXTRA_NODE_STEP
           }
         } else if (LEAFQ) {
           // (LEAFQ housekeeping follows the NODE step below)
