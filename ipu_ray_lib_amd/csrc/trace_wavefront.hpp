@@ -49,11 +49,13 @@ constexpr uint32_t kLeafQBytes = (kLeafQReqWords + 4 + 1 + 1) * 256 * 4 + 16;   
 constexpr uint32_t kLeafQEmpty = 0xFFFFFFFFu;
 
 // Scheduling weights (quarter units, NODE/TRAVERSE weigh 4) and traversal-burst limits; the defaults
-// {5, 8, 12, 32, 2} are the measured optimum on the box scene (+-2 % plateau):
+// {5, 16, 24, 32, 2} are the measured optimum on the box scene (+-2 % plateau):
 //   leafAt   inside a traversal burst, LEAF runs when cL*leafAt > cN*4
 //   shadeAt, genAt   top-level vote: SHADE/GEN run when their weighted population exceeds (cN+cL)*4
 //   burst    at most this many NODE/LEAF steps before the wave re-votes
 //   keep8    ... or earlier, once fewer than keep8/8 of the lanes that started the burst still traverse
+//   dbl, maxExtra   a NODE turn runs 1 + min(lanes / dbl, maxExtra) box tests before the wave votes again
+//   leafThenNode    a box test follows every LEAF turn at once
 struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, tradeAt, qPush = 4, qServe = 48, dbl = 6, maxExtra = 5, leafThenNode = 1; };
 
 // Per-launch extras for renders with the NIF environment. The reference traces ONE sample, evaluates the
