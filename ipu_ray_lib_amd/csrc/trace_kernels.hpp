@@ -78,10 +78,12 @@ __device__ __forceinline__ Shear make_shear(f3 d) {
 }
 
 __device__ __forceinline__ f3 permute_kz(f3 p, uint32_t kz) {
-  // (kx,ky,kz) is the cyclic rotation that puts component kz last
-  if (kz == 2) return p;
-  if (kz == 0) return mk(p.y, p.z, p.x);
-  return mk(p.z, p.x, p.y);
+  // (kx,ky,kz) is the cyclic rotation that puts component kz last. Written as selects: as three early returns
+  // hipcc built divergent regions (exec-mask juggling, ~50 scalar instructions in dependent chains per
+  // primitive test) out of what is six v_cndmask per vector.
+  const bool r1 = kz == 0;   // (1, 2, 0)
+  const bool r2 = kz == 1;   // (2, 0, 1)
+  return mk(r1 ? p.y : (r2 ? p.z : p.x), r1 ? p.z : (r2 ? p.x : p.y), r1 ? p.x : (r2 ? p.y : p.z));
 }
 
 // Mesh.cpp:6-104 (ALLOW_DOUBLE_FALLBACK=0), tFar = inf as passed by Mesh.hpp:92. Returns t (0 = miss).
