@@ -6,6 +6,8 @@ names every destination in its wait statements, which pins ORDER but not ALLOCAT
 device code to assembly (no GPU needed) and checks every kept instantiation of nif_mlp_kernel:
   * between an asm global_load / ds_read and the hand-written s_waitcnt that retires it, no other instruction reads
     or writes the destination registers (straight-line scan per kernel, in-order completion per counter);
+  * no compiler-issued vector-memory instruction is in flight together with the asm loads (it would shift the
+    hand-written vmcnt counts);
   * the kernels use no scratch (a spill of an in-flight destination would not show as a register access)."""
 import re
 import shutil
@@ -52,8 +54,17 @@ def audit(lines):
             if m:
                 n = int(m.group(1)); lg = lg[len(lg) - n:] if 0 < n < len(lg) else ([] if n == 0 else lg)
             continue
+        if op == "s_branch":
+            # what follows an unconditional branch is not its fall-through: its predecessors are scanned where they
+            # lie (the loop-carried sets reach a loop header from the prologue just above it as well)
+            vm, lg = [], []
+            continue
         if op.startswith("s_"):
             continue
+        if vm and re.match(r"(global|scratch|buffer|flat)_(load|store|atomic)", op):
+            # a compiler-issued VMEM operation joins the in-order queue the hand-written vmcnt(N) counts: with one
+            # more operation outstanding, "N left" no longer means "the oldest set has landed"
+            bad.append(f"line {i + 1}: compiler-issued '{t[:60]}' while asm loads from line {vm[0][1] + 1} are in flight")
         used = set()
         for a in args:
             used |= _regs(a)
@@ -90,3 +101,24 @@ def test_nif_kernel_asm_loads_are_not_touched_before_their_wait(tmp_path):
         assert not bad, (k, bad[:5])
         m = re.search(re.escape(k) + r":.*?; ScratchSize: (\d+)", meta, re.S)
         assert m and int(m.group(1)) == 0, (k, "uses scratch", m and m.group(1))
+
+
+def test_audit_flags_what_it_should():
+    """The scanner itself, on hand-written snippets."""
+    ok = """
+\t;;#ASMSTART
+\tglobal_load_dwordx4 v[10:13], v2, s[4:5]
+\t;;#ASMEND
+\tv_add_u32_e32 v3, 1, v3
+\t;;#ASMSTART
+\ts_waitcnt vmcnt(0)
+\t;;#ASMEND
+\tv_mfma_f32_16x16x32_f16 v[20:23], v[10:13], v[30:33], v[20:23]
+""".split("\\n")
+    assert audit(ok)[0] == []
+    touched = [l.replace("v_add_u32_e32 v3, 1, v3", "v_mov_b32_e32 v40, v11") for l in ok]
+    assert len(audit(touched)[0]) == 1
+    extra_load = [l.replace("v_add_u32_e32 v3, 1, v3", "global_load_dword v50, v[6:7], off") for l in ok]
+    assert len(audit(extra_load)[0]) == 1
+    early_use = [l.replace("s_waitcnt vmcnt(0)", "s_waitcnt vmcnt(1)") for l in ok]
+    assert len(audit(early_use)[0]) == 1
