@@ -114,7 +114,7 @@ def test_audit_flags_what_it_should():
 \ts_waitcnt vmcnt(0)
 \t;;#ASMEND
 \tv_mfma_f32_16x16x32_f16 v[20:23], v[10:13], v[30:33], v[20:23]
-""".split("\\n")
+""".split("\n")
     assert audit(ok)[0] == []
     touched = [l.replace("v_add_u32_e32 v3, 1, v3", "v_mov_b32_e32 v40, v11") for l in ok]
     assert len(audit(touched)[0]) == 1
