@@ -225,7 +225,10 @@ __device__ __forceinline__ void nif_dense_layer(const NifParams& P, const NifLay
   // pressure: the .s showed "load, s_waitcnt vmcnt(0), mfma" every k-step), so the loads are inline asm, invisible
   // to its scheduler, and their completion is counted by hand (cdna_hip_programming.md §5.7 form ii): loads return
   // in order, every step issues exactly TN of them, so "all but the newest 2*TN have landed" is the set about to be
-  // used. Every destination is named "+v" in the wait, which keeps the consumers below it.
+  // used. Every destination is named "+v" in the wait, which keeps the consumers below it. The counts assume that
+  // nothing else joins the queue inside the k-loop: no compiler-issued global or scratch access may be in flight
+  // together with these loads (tests/test_asm_pipeline_audit.py checks the generated code for that, for copies or
+  // reuse of a destination before its wait, and for scratch).
   h8 wA[TN], wB[TN], wC[TN];
   const uint32_t kSteps = L.kSteps, kLast = kSteps - 1;
   // Fragment (nt, ks) is 1 KiB at weights + wOffset + (nt*kSteps + ks)*64 (+ lane): a wave-uniform base, so the
