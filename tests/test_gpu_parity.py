@@ -581,3 +581,34 @@ def test_nif_render_sample_batching_is_order_exact(scenes, spl, monkeypatch):
     irl.IpuScene(d).close()                                  # restore the defaults for later tests
     assert_streams_identical(batched, literal, f"NIF render, {spl} samples per launch")
     assert np.stack([batched["rgb"][k] for k in "xyz"], 1).max() > 0
+
+
+def test_randomised_render_parameters_against_oracle(scenes):
+    """Twelve seeded random combinations of scene, image size, crop window, samples, seed, jitter, path length and
+    roulette depth: the whole TraceResult stream must equal the oracle's bit for bit every time (the scheduling of
+    the persistent kernel - tile order, chunked work hand-out, multi-step traversal turns - must never show)."""
+    rng = np.random.default_rng(20240611)
+    names = ["box-simple", "box", "spheres"]
+    for case in range(12):
+        name = names[case % 3]
+        s = scenes[name]; d = s.desc
+        w = int(rng.integers(3, 20)) * 8 + int(rng.integers(0, 2)) * int(rng.integers(1, 8))     # multiples of 8 and ragged widths
+        h = int(rng.integers(3, 20)) * 8 + int(rng.integers(0, 2)) * int(rng.integers(1, 8))
+        crop = None
+        if rng.random() < 0.5:
+            cw, ch = int(rng.integers(1, w + 1)), int(rng.integers(1, h + 1))
+            crop = (cw, ch, int(rng.integers(0, w - cw + 1)), int(rng.integers(0, h - ch + 1)))
+        d.set_image(w, h, crop)
+        d.samples_per_pixel = int(rng.integers(1, 24))
+        d.rng_seed = int(rng.integers(0, 2**63))
+        d.anti_alias_scale = float(rng.choice([0.0, 0.25, 1.0]))
+        d.max_path_length = int(rng.integers(1, 12))
+        d.roulette_start_depth = int(rng.integers(0, 6))
+        d.path_trace = 1
+        dev = irl.IpuScene(d)
+        got = s.init_ray_stream(); want = got.copy()
+        dev.run(got, irl.MODE_PATH_TRACE)
+        ol.path_trace_pixel_rng(d, want, 16)
+        assert_streams_identical(got, want, f"case {case}: {name} {w}x{h} crop={crop} spp={d.samples_per_pixel} len={d.max_path_length}")
+        dev.close()
+        d.set_image(96, 64); d.anti_alias_scale = 0.25; d.max_path_length = 10; d.roulette_start_depth = 3; d.rng_seed = 1442
