@@ -160,10 +160,16 @@ MI_HD uint32_t f2u_sat(float f) {
   return (uint32_t)f;
 }
 // Per-pixel stream: seeded from the user seed and FULL-image (row, col).
-MI_HD void rng_seed_pixel(Rng& r, uint64_t userSeed, float row, float col) {
+// A pixel's samples are cut into segments of kSegmentSamples; segment j has its own stream (j = 0: the plain
+// per-pixel seed) and its own partial rgb sum, added in segment order. The work atom of the
+// persistent kernel is (pixel, segment): with pixel x all-samples atoms a 1440^2 x 1000 spp frame gives every
+// lane only 6 atoms, and the drain at the end of the frame cost a third of the throughput.
+constexpr uint32_t kSegmentSamples = 128;
+MI_HD void rng_seed_pixel_segment(Rng& r, uint64_t userSeed, float row, float col, uint32_t segment) {
   const uint64_t pix = ((uint64_t)f2u_sat(row) << 32) | (uint64_t)f2u_sat(col);
-  rng_seed(r, userSeed ^ ((pix + 1ull) * 0x9e3779b97f4a7c15ull));
+  rng_seed(r, (userSeed ^ ((pix + 1ull) * 0x9e3779b97f4a7c15ull)) ^ ((uint64_t)segment * 0xd1b54a32d192ed03ull));
 }
+MI_HD void rng_seed_pixel(Rng& r, uint64_t userSeed, float row, float col) { rng_seed_pixel_segment(r, userSeed, row, col, 0u); }
 
 // Deterministic ln(x), x normal and positive (pixel-jitter Box-Muller only).
 MI_HD float log_det(float x) {

@@ -79,6 +79,7 @@ struct mi_scene {
   std::vector<void*> allocations;
   unsigned long long* d_counters = nullptr;
   uint32_t* d_workCounter = nullptr;
+  float* d_segPart = nullptr; size_t segPartFloats = 0;     // partial rgb sums of segmented pixels, [segments][n][3]
   double traceTimeSecs = 0.0;
   float hdriRotationDegrees = 0.f;
   size_t maxNifBatch = 0;
@@ -98,6 +99,7 @@ struct mi_scene {
     if (d_bgr) (void)hipFree(d_bgr);
     if (d_slotColor) (void)hipFree(d_slotColor);
     if (d_slotTp) (void)hipFree(d_slotTp);
+    if (d_segPart) (void)hipFree(d_segPart);
     nif.release();
   }
   template <class T> T* keep(T* p) { if (p) allocations.push_back((void*)p); return p; }
@@ -266,6 +268,28 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
   const uint32_t tileW = (!noTiles && w >= 8 && (w % 8) == 0 && cnt >= 8u * w) ? w : 0u;
   HIP_CHECK(hipMemsetAsync(workCounter, 0, sizeof(uint32_t), stream));
   const bool plain = ex.rngState == nullptr;      // the sample-at-a-time form only exists for the default kernel
+  // Pixels with more than kSegmentSamples samples are traced as (pixel, segment) work atoms (ray_math.h); the two
+  // pipeline slots of mi_render run on different streams, so only slot 0 may use the shared partial-sum buffer and
+  // slot 1 (and the two-rays-per-lane variant, which keeps rgb in memory) falls back to the nested-loop kernel's
+  // in-thread segment loop - the results are the same by definition.
+  WaveExtras exs = ex;
+  const uint32_t segments = (S.ds.samplesPerPixel + kSegmentSamples - 1) / kSegmentSamples;
+  const bool segmented = plain && segments > 1;
+  if (segmented) {
+    if ((uint64_t)cnt * segments > 0xFFFFFFFFull) throw ArgError("mi_render: too many (pixel, segment) work items in one launch (cut the stream with mi_scene_set_ray_batch)");
+    const size_t need = (size_t)3 * cnt * segments;
+    if (S.segPartFloats < need) {
+      if (S.d_segPart) (void)hipFree(S.d_segPart);
+      S.d_segPart = nullptr; S.segPartFloats = 0;
+      HIP_CHECK(hipMalloc(&S.d_segPart, need * sizeof(float)));
+      S.segPartFloats = need;
+    }
+    exs.segPart = S.d_segPart; exs.segments = segments;
+  }
+  struct CombineAfter {      // runs the per-pixel sum of the partials once the trace kernel has been enqueued
+    mi_scene& S; mi_trace_result* rays; uint32_t cnt, segments; hipStream_t stream; bool on;
+    ~CombineAfter() { if (on) hipLaunchKernelGGL(segment_combine_kernel, dim3((cnt + 255) / 256), dim3(256), 0, stream, rays, cnt, segments, S.d_segPart); }
+  } combineAfter{S, d_rays, cnt, segments, stream, segmented};
   if (plain && g_kernelChoice == 2 && S.ds.numNodes > 0) {
     // one 1024-thread workgroup per CU shares one LDS copy of the first nodes of the (preorder) array
     const uint32_t ldsNodes = std::min<uint32_t>(S.ds.numNodes, kLdsBudgetBytes / (uint32_t)sizeof(GNode));
@@ -274,27 +298,27 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
     static bool attrSet = false;
     if (!attrSet) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes)); attrSet = true; }
     const uint32_t blocks = std::min<uint32_t>((cnt + 1023) / 1024, 256);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, ldsNodes, g_tune, tileW, ex);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, ldsNodes, g_tune, tileW, exs);
   } else if (plain && g_kernelChoice == 3 && !S.ds.hasNormals) {
     // two rays per lane, the second parked in LDS: 9 uint4 groups x 64 lanes x 4 waves = 36 KiB per workgroup
     const size_t ldsBytes = (size_t)kParkBytesPerWave * (256 / 64);
     const uint32_t blocks = std::min<uint32_t>((cnt + 511) / 512, 256 * 4);
-    hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, true>), dim3(blocks), dim3(256), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, ex);
+    hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, true>), dim3(blocks), dim3(256), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, exs);
   } else if (g_kernelChoice == 4) {
     // primitive tests pooled across the workgroup (LEAFQ): 17 KiB of LDS per workgroup
     const bool five = !STATS && g_wavesPerSimd == 5;
     const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, 256 * 8);
     if (five)
-      hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, false, 5, true>), dim3(blocks), dim3(256), kLeafQBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, ex);
+      hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, false, 5, true>), dim3(blocks), dim3(256), kLeafQBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, exs);
     else
-      hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, false, 4, true>), dim3(blocks), dim3(256), kLeafQBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, ex);
+      hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, false, 4, true>), dim3(blocks), dim3(256), kLeafQBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, exs);
   } else if (!STATS && g_wavesPerSimd == 5) {
     // 96-VGPR build: 5 waves per SIMD (+4.6 % on the box scene; 6 waves = 80 VGPRs: -15 %, its spills land in LEAF/SHADE)
     const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, 256 * 8);
-    hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, false, 5>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, ex);
+    hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, false, 5>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, exs);
   } else {
     const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, 256 * 8);
-    hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, false>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, ex);
+    hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, false>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, exs);
   }
 }
 
@@ -308,7 +332,9 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
     if (g_fullStats) hipLaunchKernelGGL(shadow_trace_kernel<true>, grid, block, 0, stream, S.ds, d_rays, cnt, .05f, light);
     else hipLaunchKernelGGL(shadow_trace_kernel<false>, grid, block, 0, stream, S.ds, d_rays, cnt, .05f, light);
   } else if (mode == MI_MODE_PATH_TRACE) {
-    if (!S.nif.loaded() && g_kernelChoice != 0 && S.ds.samplesPerPixel >= 1 && S.ds.maxPathLength >= 1) {
+    const bool segmentedFrame = S.ds.samplesPerPixel > kSegmentSamples;
+    const bool waveOk = !(segmentedFrame && (slot != 0 || g_kernelChoice == 3));     // see launchWavefront
+    if (!S.nif.loaded() && g_kernelChoice != 0 && waveOk && S.ds.samplesPerPixel >= 1 && S.ds.maxPathLength >= 1) {
       // sample loop inside the kernel (src/IpuScene.cpp:441), phase-scheduled persistent form
       if (g_fullStats) launchWavefront<true>(S, d_rays, cnt, stream, slot);
       else launchWavefront<false>(S, d_rays, cnt, stream, slot);

@@ -76,6 +76,11 @@ struct WaveExtras {
   uint32_t* index = nullptr; uint32_t* count = nullptr;
   float azimuthRotation = 0.f;
   uint32_t fetchChunk = 0;       // work indices taken per global atomic (multiple of 64; 0 = 64)
+  // Segmented pixels (ray_math.h kSegmentSamples): the work atom is (pixel, segment), work index = segment * n + i;
+  // every atom leaves its partial rgb sum in segPart[segment][pixel] (segment 0 starts from the incoming rgb) and
+  // segment_combine_kernel adds them in segment order afterwards; the last segment writes the hit record.
+  float* segPart = nullptr;      // [segments][n][3]
+  uint32_t segments = 1;
 };
 
 template <bool STATS, bool LDS_NODES, int BLOCK, bool TWO_RAYS, int WAVES_PER_SIMD = 4, bool LEAFQ = false>
@@ -111,6 +116,8 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
   const uint32_t tiledCount = tileStreamW ? (n / (8u * tileStreamW)) * (8u * tileStreamW) : 0u;
   const uint32_t numNodes = sc.numNodes;
   const uint32_t spp = ex.sampleCount ? ex.sampleCount : sc.samplesPerPixel;
+  const uint32_t segs = (!TWO_RAYS && ex.segPart) ? ex.segments : 1u;
+  const uint32_t items = n * segs;                 // (host checks that this fits 32 bits)
 
   // ---- lane state ----
   uint32_t ph = PH_FETCH;
@@ -314,14 +321,16 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
       chunkNext += min((uint32_t)__popcll(mF), avail);
       if (ph == PH_FETCH && rankF < avail) {
         const uint32_t idx = chunkBase + rankF;
-        if (idx < n) {
+        if (idx < items) {
           // When the stream is made of full rows of width tileStreamW (a multiple of 8), consecutive work indices
           // walk 8x8 pixel tiles over each complete group of 8 rows (the remainder keeps stream order), so the
           // 64 pixels a wave starts with are a compact tile whose primary rays traverse alike. The map is a
           // bijection on [0, n) and any order gives the same image: every pixel owns its RNG stream.
-          uint32_t entry = idx;
-          if (tileStreamW && idx < tiledCount) {
-            const uint32_t t = idx >> 6, within = idx & 63u, perRow = tileStreamW >> 3;
+          uint32_t seg = 0, pidx = idx;
+          if (segs > 1) { seg = idx / n; pidx = idx - seg * n; }
+          uint32_t entry = pidx;
+          if (tileStreamW && pidx < tiledCount) {
+            const uint32_t t = pidx >> 6, within = pidx & 63u, perRow = tileStreamW >> 3;
             entry = ((t / perRow) * 8u + (within >> 3)) * tileStreamW + (t % perRow) * 8u + (within & 7u);
           }
           pix = entry;
@@ -329,11 +338,12 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
           prow = res->u; pcol = res->v;
           if (!TWO_RAYS) {                                                // TWO_RAYS accumulates rgb in memory
             coldU(0) = entry; coldF(1) = prow; coldF(2) = pcol;
-            coldF(3) = res->rgb.x; coldF(4) = res->rgb.y; coldF(5) = res->rgb.z;
+            if (seg == 0) { coldF(3) = res->rgb.x; coldF(4) = res->rgb.y; coldF(5) = res->rgb.z; }
+            else { coldF(3) = 0.f; coldF(4) = 0.f; coldF(5) = 0.f; }           // a later segment's own partial sum
           }
           if (ex.rngState && !ex.seedNow) rng = ex.rngState[entry];
-          else rng_seed_pixel(rng, sc.rngSeed, prow, pcol);
-          sample = 0;
+          else rng_seed_pixel_segment(rng, sc.rngSeed, prow, pcol, seg);
+          sample = seg * kSegmentSamples;
           pathStore();                 // (GEN initialises the rest)
           ph = PH_GEN;
         } else {
@@ -570,9 +580,19 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
           else { coldF(3) = coldF(3) + color.x; coldF(4) = coldF(4) + color.y; coldF(5) = coldF(5) + color.z; }
           ++paths;
           ++sample;
-          if (sample < spp) ph = PH_GEN;
-          else {
+          const bool more = segs > 1 ? ((sample & (kSegmentSamples - 1u)) != 0u && sample < spp) : (sample < spp);
+          if (more) ph = PH_GEN;
+          else if (segs > 1 && sample < spp) {
+            // a segment other than the last is complete: its partial sum is all it leaves
+            float* part = ex.segPart + 3 * ((size_t)((sample - 1u) / kSegmentSamples) * n + pixNow);
+            part[0] = coldF(3); part[1] = coldF(4); part[2] = coldF(5);
+            ph = PH_FETCH;
+          } else {
             // pixel complete: rgb sum + the LAST sample's hit record
+            if (segs > 1) {
+              float* part = ex.segPart + 3 * ((size_t)((sample - 1u) / kSegmentSamples) * n + pixNow);
+              part[0] = coldF(3); part[1] = coldF(4); part[2] = coldF(5);
+            } else
             if (!TWO_RAYS && !ex.slotColor) res->rgb = {coldF(3), coldF(4), coldF(5)};
             uint32_t oPrim = MI_INVALID_PRIM, oGeom = MI_INVALID_GEOM;
             const uint32_t lastLeaf = TWO_RAYS ? oLeaf : coldU(6);
@@ -666,6 +686,18 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
     atomicAdd(&sc.counters[12], tTrav); atomicAdd(&sc.counters[13], tShade); atomicAdd(&sc.counters[14], tGen);
     atomicAdd(&sc.counters[15], __builtin_amdgcn_s_memtime() - tLoop0);
   }
+}
+
+// rgb of a segmented pixel: ((segment 0, which started from the incoming rgb) + segment 1) + ... in segment order.
+__global__ void __launch_bounds__(256) segment_combine_kernel(mi_trace_result* rays, uint32_t n, uint32_t segments, const float* __restrict__ part) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  f3 rgb = mk(part[3 * (size_t)i], part[3 * (size_t)i + 1], part[3 * (size_t)i + 2]);
+  for (uint32_t s = 1; s < segments; ++s) {
+    const size_t q = 3 * ((size_t)s * n + i);
+    rgb = rgb + mk(part[q], part[q + 1], part[q + 2]);
+  }
+  rays[i].rgb = {rgb.x, rgb.y, rgb.z};
 }
 
 }  // namespace mi

@@ -612,3 +612,31 @@ def test_randomised_render_parameters_against_oracle(scenes):
         assert_streams_identical(got, want, f"case {case}: {name} {w}x{h} crop={crop} spp={d.samples_per_pixel} len={d.max_path_length}")
         dev.close()
         d.set_image(96, 64); d.anti_alias_scale = 0.25; d.max_path_length = 10; d.roulette_start_depth = 3; d.rng_seed = 1442
+
+
+@pytest.mark.parametrize("kernel", ["0", "1", "2", "3", "4"])
+def test_segmented_pixels_bit_exact(scenes, kernel, monkeypatch):
+    """More than 128 samples per pixel: the pixel is traced as segments of 128 samples, each with its own RNG stream
+    and partial rgb sum, added in segment order. 300 spp = two full segments + one of 44; the incoming
+    rgb is non-zero (segment 0 accumulates onto it). Every kernel variant - the persistent kernel traces (pixel,
+    segment) work atoms, the nested-loop kernel loops over the segments in one thread, the two-rays variant falls
+    back to it - must reproduce the oracle bit for bit; so must a batched render (second pipeline slot)."""
+    monkeypatch.setenv("MI_RAYLIB_KERNEL", kernel)
+    s = scenes["box"]; d = s.desc
+    d.set_image(72, 40); d.samples_per_pixel = 300; d.path_trace = 1
+    dev = irl.IpuScene(d)
+    got = s.init_ray_stream()
+    rng = np.random.default_rng(3)
+    for k in "xyz":
+        got["rgb"][k] = rng.random(got.size).astype(np.float32)
+    want = got.copy(); batched = got.copy()
+    dev.run(got, irl.MODE_PATH_TRACE)
+    st = ol.path_trace_pixel_rng(d, want, 16)
+    assert_streams_identical(got, want, f"segmented pixels, kernel {kernel}")
+    assert dev.counters()["casts"] == st.casts
+    dev.setRayBatch(1000)
+    dev.run(batched, irl.MODE_PATH_TRACE)
+    assert_streams_identical(batched, want, f"segmented pixels in batches, kernel {kernel}")
+    dev.close()
+    monkeypatch.setenv("MI_RAYLIB_KERNEL", "1")
+    irl.IpuScene(d).close()
