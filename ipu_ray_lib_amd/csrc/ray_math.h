@@ -164,7 +164,7 @@ MI_HD uint32_t f2u_sat(float f) {
 // per-pixel seed) and its own partial rgb sum, added in segment order. The work atom of the
 // persistent kernel is (pixel, segment): with pixel x all-samples atoms a 1440^2 x 1000 spp frame gives every
 // lane only 6 atoms, and the drain at the end of the frame cost a third of the throughput.
-constexpr uint32_t kSegmentSamples = 128;
+constexpr uint32_t kSegmentSamples = 64;
 MI_HD void rng_seed_pixel_segment(Rng& r, uint64_t userSeed, float row, float col, uint32_t segment) {
   const uint64_t pix = ((uint64_t)f2u_sat(row) << 32) | (uint64_t)f2u_sat(col);
   rng_seed(r, (userSeed ^ ((pix + 1ull) * 0x9e3779b97f4a7c15ull)) ^ ((uint64_t)segment * 0xd1b54a32d192ed03ull));

@@ -741,7 +741,7 @@ static uint32_t f2u_sat(float f) {
  * has its own stream, seeded from (seed, row, col, j) - j = 0 is the plain per-pixel seed - and its own partial
  * rgb sum; the pixel's rgb is ((rgb_in + segment 0) + segment 1) + ... in segment order, segment 0 accumulating
  * onto rgb_in directly. For samplesPerPixel <= O_SEGMENT_SAMPLES this is one stream and one running sum. */
-#define O_SEGMENT_SAMPLES 128u
+#define O_SEGMENT_SAMPLES 64u
 static void pixel_stream_seed_segment(uint64_t s[2], uint64_t rngSeed, float pu, float pv, uint32_t segment) {
   const uint64_t pix = ((uint64_t)f2u_sat(pu) << 32) | (uint64_t)f2u_sat(pv);
   o_xoshiro_seed(s, (rngSeed ^ ((pix + 1ull) * 0x9e3779b97f4a7c15ull)) ^ ((uint64_t)segment * 0xd1b54a32d192ed03ull));

@@ -616,8 +616,8 @@ def test_randomised_render_parameters_against_oracle(scenes):
 
 @pytest.mark.parametrize("kernel", ["0", "1", "2", "3", "4"])
 def test_segmented_pixels_bit_exact(scenes, kernel, monkeypatch):
-    """More than 128 samples per pixel: the pixel is traced as segments of 128 samples, each with its own RNG stream
-    and partial rgb sum, added in segment order. 300 spp = two full segments + one of 44; the incoming
+    """More than 64 samples per pixel: the pixel is traced as segments of 64 samples, each with its own RNG stream
+    and partial rgb sum, added in segment order. 300 spp = four full segments + one of 44; the incoming
     rgb is non-zero (segment 0 accumulates onto it). Every kernel variant - the persistent kernel traces (pixel,
     segment) work atoms, the nested-loop kernel loops over the segments in one thread, the two-rays variant falls
     back to it - must reproduce the oracle bit for bit; so must a batched render (second pipeline slot)."""
