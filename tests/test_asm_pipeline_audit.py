@@ -79,7 +79,7 @@ def audit(lines):
 @pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not available")
 def test_nif_kernel_asm_loads_are_not_touched_before_their_wait(tmp_path):
     out = tmp_path / "raylib.s"
-    cmd = [HIPCC, "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-function",
+    cmd = [HIPCC, "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wno-unused-function",
            "-I", str(ROOT / "include"), "-S", "--cuda-device-only", "-o", str(out), str(ROOT / "ipu_ray_lib_amd" / "csrc" / "raylib.hip")]
     subprocess.run(cmd, check=True, capture_output=True, timeout=600)
     text = out.read_text().split("\n")
