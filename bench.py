@@ -208,6 +208,7 @@ def main():
         "casts_per_path": total_casts / max(total_paths, 1.0),
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     "note": "algorithmic scene bytes are served by L1/L2 (the scene is < 1 MB), so this fraction can exceed 1; `traffic` is the HBM traffic of a launch",
                      "kernel": "path_trace_wavefront_kernel", "avg_launch_ms": avg_kernel_s * 1e3,
                      "bytes_per_cast": bytes_per_cast, "nodes_per_cast": nodes_per_cast, "leaf_tests_per_cast": leaf_per_cast},
     }
