@@ -49,7 +49,7 @@ constexpr uint32_t kLeafQBytes = (kLeafQReqWords + 4 + 1 + 1) * 256 * 4 + 16;   
 constexpr uint32_t kLeafQEmpty = 0xFFFFFFFFu;
 
 // Scheduling weights (quarter units, NODE/TRAVERSE weigh 4) and traversal-burst limits; the defaults
-// {5, 16, 24, 32, 2} are the measured optimum on the box scene (+-2 % plateau):
+// {5, 16, 24, 48, 3} are the measured optimum on the box scene (+-2 % plateau):
 //   leafAt   inside a traversal burst, LEAF runs when cL*leafAt > cN*4
 //   shadeAt, genAt   top-level vote: SHADE/GEN run when their weighted population exceeds (cN+cL)*4
 //   burst    at most this many NODE/LEAF steps before the wave re-votes
