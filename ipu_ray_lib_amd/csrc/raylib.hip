@@ -224,13 +224,13 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
   S.keep(S.d_workCounter);
 }
 
-  // slots per pixel per launch in NIF renders (44 B each); MI_RAYLIB_NIF_SPL overrides (1..64)
+  // slots per pixel per launch in NIF renders (44 B each, default 32); MI_RAYLIB_NIF_SPL overrides (1..64)
 
 void ensureScratch(mi_scene& S, size_t n) {
   {
     const char* e = getenv("MI_RAYLIB_NIF_SPL");
-    uint32_t v = e ? (uint32_t)atoi(e) : 16u;
-    if (v < 1 || v > 64) v = 16u;
+    uint32_t v = e ? (uint32_t)atoi(e) : 32u;
+    if (v < 1 || v > 64) v = 32u;
     if (v != S.scratchSamples) { S.scratchSamples = v; S.scratchRays = 0; }     // slot buffers are sized for n x v
   }
   if (S.scratchRays >= n) return;

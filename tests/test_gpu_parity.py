@@ -552,10 +552,10 @@ def test_rank_streams_render_like_the_whole_frame(scenes, world):
     dev.close()
 
 
-@pytest.mark.parametrize("spl", ["16", "4", "1"])
+@pytest.mark.parametrize("spl", ["32", "4", "1"])
 def test_nif_render_sample_batching_is_order_exact(scenes, spl, monkeypatch):
     """NIF renders trace several samples per launch and replay the reference's per-sample order afterwards
-    (rgb += radiance, then rgb += throughput * env). Whatever the samples-per-launch setting (16 default, 4, 1;
+    (rgb += radiance, then rgb += throughput * env). Whatever the samples-per-launch setting (32 default, 4, 1;
     19 spp is a multiple of none), the whole TraceResult stream must equal, bit for bit, the literal per-sample loop
     {trace 1 sample; uv pre-pass; MLP; env add} that MI_RAYLIB_KERNEL=0 still runs with the nested-loop kernel."""
     rng = np.random.default_rng(8)
@@ -577,7 +577,7 @@ def test_nif_render_sample_batching_is_order_exact(scenes, spl, monkeypatch):
 
     literal = render("0")
     batched = render("1")
-    monkeypatch.setenv("MI_RAYLIB_KERNEL", "1"); monkeypatch.setenv("MI_RAYLIB_NIF_SPL", "16")
+    monkeypatch.setenv("MI_RAYLIB_KERNEL", "1"); monkeypatch.setenv("MI_RAYLIB_NIF_SPL", "32")
     irl.IpuScene(d).close()                                  # restore the defaults for later tests
     assert_streams_identical(batched, literal, f"NIF render, {spl} samples per launch")
     assert np.stack([batched["rgb"][k] for k in "xyz"], 1).max() > 0
