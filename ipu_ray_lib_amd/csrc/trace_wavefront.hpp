@@ -407,8 +407,10 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
       // lanes only change rays in SHADE/GEN (or in a trade), so "some lane needs the literal box test" is a
       // per-burst fact
       bool anyExact = __ballot(exactSlab) != 0ull;
-      auto nodeStep = [&]() {
-        if (ph == PH_NODE) {
+      // One box test of a lane that is in the NODE phase; returns whether the lane is still in it afterwards, so that
+      // back-to-back tests narrow the exec mask from that condition directly instead of re-reading `ph`.
+      auto nodeBody = [&]() -> bool {
+        {
           GNode nd;
           // (uniform base + 32-bit byte offset: the load takes the scalar-base form, one shift instead of 64-bit address math)
           if (LDS_NODES && node < ldsNodeCount) nd = ldsNodes[node];
@@ -441,12 +443,14 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
           if (boxHit && isLeaf) {
             pendLeaf = nd.link;
             ph = PH_LEAF;
-          } else {
-            node = (boxHit || isLeaf) ? node + 1 : nd.link;
-            if (node >= numNodes) ph = PH_SHADE;
+            return false;
           }
+          node = (boxHit || isLeaf) ? node + 1 : nd.link;
+          if (node >= numNodes) { ph = PH_SHADE; return false; }
+          return true;
         }
       };
+      auto nodeStep = [&]() { if (ph == PH_NODE) (void)nodeBody(); };
       for (;;) {
         const uint32_t stay = cN;
         if (LEAFQ ? (cN > 0) : (cN * 4u >= cL * tune.leafAt && cN > 0)) {
@@ -454,14 +458,28 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
           // votes again (tune.dbl): a vote costs a ballot-popcount-branch chain whose latency the second test hides;
           // lanes that reached a leaf in the first simply sit the second out.
           if (STATS) { itN++; lnN += stay; }
-          nodeStep();
-          if (!LEAFQ && !TWO_RAYS) {
-            const uint32_t extra = min(stay / tune.dbl, tune.maxExtra);
-            // (spelled out rather than looped: straight-line code lets the next test's node load issue under the
-            //  previous test's arithmetic)
-#define MI_EXTRA_NODE_STEP(k) if (extra >= k) { if (STATS) { itN++; lnN += (uint32_t)__popcll(__ballot(ph == PH_NODE)); } nodeStep(); ++steps; }
-            MI_EXTRA_NODE_STEP(1) MI_EXTRA_NODE_STEP(2) MI_EXTRA_NODE_STEP(3) MI_EXTRA_NODE_STEP(4) MI_EXTRA_NODE_STEP(5)
-#undef MI_EXTRA_NODE_STEP
+          if (LEAFQ || TWO_RAYS) nodeStep();
+          else {
+            const uint32_t extra = min(stay / tune.dbl, tune.maxExtra);       // wave-uniform
+            if (STATS) {
+              // instrumented build: the same tests, one exec region each, counted
+              nodeStep();
+              for (uint32_t e = 0; e < extra; ++e) { itN++; lnN += (uint32_t)__popcll(__ballot(ph == PH_NODE)); nodeStep(); }
+            } else if (ph == PH_NODE) {
+              // spelled out rather than looped: straight-line code, and each further test runs under the previous
+              // one's "still walking" condition instead of re-reading `ph`
+              bool go = nodeBody();
+              if (extra >= 1 && go) { go = nodeBody();
+                if (extra >= 2 && go) { go = nodeBody();
+                  if (extra >= 3 && go) { go = nodeBody();
+                    if (extra >= 4 && go) { go = nodeBody();
+                      if (extra >= 5 && go) (void)nodeBody();
+                    }
+                  }
+                }
+              }
+            }
+            steps += extra;
           }
         } else if (LEAFQ) {
           // (LEAFQ housekeeping follows the NODE step below)
