@@ -7,10 +7,14 @@
 //     LEAF  one primitive test at a leaf whose box was hit   (Mesh.cpp:6-104, Primitives.cpp:24-67)
 //     SHADE traversal finished: hit update, BxDF, roulette   (codelets/TraceCodelets.cpp:214-257)
 //     GEN   next sample's camera ray                          (codelets/TraceCodelets.cpp:142-164)
-//     FETCH pixel finished: write it back, take another one from the global work counter
+//     FETCH work unit finished: write it back, take another one from the global work counter
 // and each loop iteration the wave votes (ballot + popcount, scalar) and runs the phase most of its
 // lanes are waiting in. A lane that finishes a path immediately starts its next sample, a lane that
-// finishes a pixel pulls a new one, so no lane idles until the frame runs out of pixels. Each lane
+// finishes a work unit - a pixel, or a 64-sample segment of one (ray_math.h) - pulls a new one, so no lane
+// idles until the frame runs out of work; units are small on purpose, the drain at the end of a frame is paid
+// per unit. The kernel is bound by the latency of each wave's dependent chain (node load -> box test -> vote),
+// so the scheduling below is about few, short chains: several box tests per vote, whole 8x8 tiles per wave,
+// cold state in LDS so that five waves fit a SIMD. Each lane
 // still performs exactly the reference's sequence of operations for its rays, in the reference's
 // order, with the same arithmetic — only the interleaving between lanes changes — so results stay
 // bit-identical to the nested-loop kernel and to the CPU oracle.
