@@ -405,7 +405,7 @@ int mi_scene_create(const mi_scene_desc* desc, mi_scene** out) {
     S->params.mesh_normals = nullptr; S->params.mat_ids = nullptr; S->params.materials = nullptr; S->params.bvh_nodes = nullptr;
     S->params.spheres = nullptr; S->params.discs = nullptr;
     if (const char* e = getenv("MI_RAYLIB_FULL_STATS")) g_fullStats = (e[0] == '1');
-    if (const char* e = getenv("MI_RAYLIB_TUNE")) { unsigned a, b, c, dd = 48, k8 = 3, ta = 16, qp = 4, qs = 48, db = 6, mx = 5, ln = 1; if (sscanf(e, "%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u", &a, &b, &c, &dd, &k8, &ta, &qp, &qs, &db, &mx, &ln) >= 3) g_tune = {a, b, c, dd, k8, ta, qp, qs, db ? db : 65, mx, ln}; }
+    if (const char* e = getenv("MI_RAYLIB_TUNE")) { unsigned a, b, c, dd = 48, k8 = 3, ta = 16, qp = 4, qs = 48, db = 6, mx = 5, ln = 1, pr = 1; if (sscanf(e, "%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u", &a, &b, &c, &dd, &k8, &ta, &qp, &qs, &db, &mx, &ln, &pr) >= 3) g_tune = {a, b, c, dd, k8, ta, qp, qs, db ? db : 65, mx, ln, pr}; }
     if (const char* e = getenv("MI_RAYLIB_WAVES")) g_wavesPerSimd = (e[0] == '4') ? 4 : 5;
     if (const char* e = getenv("MI_RAYLIB_KERNEL")) g_kernelChoice = (e[0] == '0') ? 0 : (e[0] == '2') ? 2 : (e[0] == '3') ? 3 : (e[0] == '4') ? 4 : 1;
   });

@@ -60,7 +60,9 @@ constexpr uint32_t kLeafQEmpty = 0xFFFFFFFFu;
 //   keep8    ... or earlier, once fewer than keep8/8 of the lanes that started the burst still traverse
 //   dbl, maxExtra   a NODE turn runs 1 + min(lanes / dbl, maxExtra) box tests before the wave votes again
 //   leafThenNode    a box test follows every LEAF turn at once
-struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, tradeAt, qPush = 4, qServe = 48, dbl = 6, maxExtra = 5, leafThenNode = 1; };
+//   prio     1: waves run their traversal turns at s_setprio 1 (short dependent steps win VALU arbitration over
+//            another wave's long SHADE/GEN blocks: +1 %), 0: no priorities
+struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, tradeAt, qPush = 4, qServe = 48, dbl = 6, maxExtra = 5, leafThenNode = 1, prio = 1; };
 
 // Per-launch extras for renders with the NIF environment. The reference traces ONE sample, evaluates the
 // environment for the rays that escaped, adds it, and repeats (src/IpuScene.cpp:571-583). One sample per launch
@@ -406,6 +408,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
     if (run == 0) {
       // ---------------- TRAVERSE: NODE and LEAF steps under a two-way mini-vote ----------------
       const unsigned long long tq0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+      if (tune.prio == 1) __builtin_amdgcn_s_setprio(1); else if (tune.prio == 2) __builtin_amdgcn_s_setprio(0);
       const uint32_t startT = cN + cL;
       uint32_t steps = 0;
       // lanes only change rays in SHADE/GEN (or in a trade), so "some lane needs the literal box test" is a
@@ -540,6 +543,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
         }
         if (++steps >= tune.burst || (cN + cL) * 8u < startT * tune.keep8 || (cN + cL) == 0) break;
       }
+      if (tune.prio == 1) __builtin_amdgcn_s_setprio(0); else if (tune.prio == 2) __builtin_amdgcn_s_setprio(1);
       if (STATS) tTrav += __builtin_amdgcn_s_memtime() - tq0;
     } else if (run == 2) {
       // ---------------- SHADE: traversal of bounce `bounce` is complete ----------------
