@@ -266,59 +266,70 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
   const uint32_t w = (uint32_t)S.params.window_w;
   static const bool noTiles = getenv("MI_RAYLIB_NO_TILES") != nullptr;
   const uint32_t tileW = (!noTiles && w >= 8 && (w % 8) == 0 && cnt >= 8u * w) ? w : 0u;
-  HIP_CHECK(hipMemsetAsync(workCounter, 0, sizeof(uint32_t), stream));
   const bool plain = ex.rngState == nullptr;      // the sample-at-a-time form only exists for the default kernel
   // Pixels with more than kSegmentSamples samples are traced as (pixel, segment) work atoms (ray_math.h); the two
   // pipeline slots of mi_render run on different streams, so only slot 0 may use the shared partial-sum buffer and
   // slot 1 (and the two-rays-per-lane variant, which keeps rgb in memory) falls back to the nested-loop kernel's
   // in-thread segment loop - the results are the same by definition.
-  WaveExtras exs = ex;
   const uint32_t segments = (S.ds.samplesPerPixel + kSegmentSamples - 1) / kSegmentSamples;
   const bool segmented = plain && segments > 1;
+  // One launch covers as many segments of every pixel as the partial-sum budget holds (8 GiB, MI_RAYLIB_SEG_BUDGET_KB
+  // overrides; the bench frame needs 0.4 GB); longer renders run as several launches whose combine passes continue
+  // the running sum in segment order, so the cut never shows in the result.
+  uint32_t perLaunch = segments;
   if (segmented) {
-    if ((uint64_t)cnt * segments > 0xFFFFFFFFull) throw ArgError("mi_render: too many (pixel, segment) work items in one launch (cut the stream with mi_scene_set_ray_batch)");
-    const size_t need = (size_t)3 * cnt * segments;
+    const char* e = getenv("MI_RAYLIB_SEG_BUDGET_KB");
+    const size_t kb = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)8 * 1024 * 1024;
+    const size_t budgetFloats = std::max<size_t>(kb, 1) * (size_t)(1024 / sizeof(float));
+    const uint64_t byBudget = std::max<uint64_t>(1, budgetFloats / ((uint64_t)3 * cnt));
+    const uint64_t byIndex = std::max<uint64_t>(1, 0xFFFFFFFFull / cnt);           // work indices are 32-bit
+    perLaunch = (uint32_t)std::min<uint64_t>(segments, std::min(byBudget, byIndex));
+    const size_t need = (size_t)3 * cnt * perLaunch;
     if (S.segPartFloats < need) {
       if (S.d_segPart) (void)hipFree(S.d_segPart);
       S.d_segPart = nullptr; S.segPartFloats = 0;
       HIP_CHECK(hipMalloc(&S.d_segPart, need * sizeof(float)));
       S.segPartFloats = need;
     }
-    exs.segPart = S.d_segPart; exs.segments = segments;
   }
-  struct CombineAfter {      // runs the per-pixel sum of the partials once the trace kernel has been enqueued
-    mi_scene& S; mi_trace_result* rays; uint32_t cnt, segments; hipStream_t stream; bool on;
-    ~CombineAfter() { if (on) hipLaunchKernelGGL(segment_combine_kernel, dim3((cnt + 255) / 256), dim3(256), 0, stream, rays, cnt, segments, S.d_segPart); }
-  } combineAfter{S, d_rays, cnt, segments, stream, segmented};
-  if (plain && g_kernelChoice == 2 && S.ds.numNodes > 0) {
-    // one 1024-thread workgroup per CU shares one LDS copy of the first nodes of the (preorder) array
-    const uint32_t ldsNodes = std::min<uint32_t>(S.ds.numNodes, kLdsBudgetBytes / (uint32_t)sizeof(GNode));
-    const size_t ldsBytes = (size_t)ldsNodes * sizeof(GNode);
-    auto kern = path_trace_wavefront_kernel<STATS, true, 1024, false>;
-    static bool attrSet = false;
-    if (!attrSet) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes)); attrSet = true; }
-    const uint32_t blocks = std::min<uint32_t>((cnt + 1023) / 1024, 256);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, ldsNodes, g_tune, tileW, exs);
-  } else if (plain && g_kernelChoice == 3 && !S.ds.hasNormals) {
-    // two rays per lane, the second parked in LDS: 9 uint4 groups x 64 lanes x 4 waves = 36 KiB per workgroup
-    const size_t ldsBytes = (size_t)kParkBytesPerWave * (256 / 64);
-    const uint32_t blocks = std::min<uint32_t>((cnt + 511) / 512, 256 * 4);
-    hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, true>), dim3(blocks), dim3(256), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, exs);
-  } else if (g_kernelChoice == 4) {
-    // primitive tests pooled across the workgroup (LEAFQ): 17 KiB of LDS per workgroup
-    const bool five = !STATS && g_wavesPerSimd == 5;
-    const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, 256 * 8);
-    if (five)
-      hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, false, 5, true>), dim3(blocks), dim3(256), kLeafQBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, exs);
-    else
-      hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, false, 4, true>), dim3(blocks), dim3(256), kLeafQBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, exs);
-  } else if (!STATS && g_wavesPerSimd == 5) {
-    // 96-VGPR build: 5 waves per SIMD (+4.6 % on the box scene; 6 waves = 80 VGPRs: -15 %, its spills land in LEAF/SHADE)
-    const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, 256 * 8);
-    hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, false, 5>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, exs);
-  } else {
-    const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, 256 * 8);
-    hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, false>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, exs);
+  const uint32_t launches = segmented ? (segments + perLaunch - 1) / perLaunch : 1u;
+  for (uint32_t l = 0; l < launches; ++l) {
+    const uint32_t segBase = l * perLaunch;
+    WaveExtras exs = ex;
+    if (segmented) { exs.segPart = S.d_segPart; exs.segments = std::min(perLaunch, segments - segBase); exs.segBase = segBase; }
+    HIP_CHECK(hipMemsetAsync(workCounter, 0, sizeof(uint32_t), stream));
+    const uint64_t items = (uint64_t)cnt * (segmented ? exs.segments : 1u);     // work atoms of this launch
+    if (plain && g_kernelChoice == 2 && S.ds.numNodes > 0) {
+      // one 1024-thread workgroup per CU shares one LDS copy of the first nodes of the (preorder) array
+      const uint32_t ldsNodes = std::min<uint32_t>(S.ds.numNodes, kLdsBudgetBytes / (uint32_t)sizeof(GNode));
+      const size_t ldsBytes = (size_t)ldsNodes * sizeof(GNode);
+      auto kern = path_trace_wavefront_kernel<STATS, true, 1024, false>;
+      static bool attrSet = false;
+      if (!attrSet) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes)); attrSet = true; }
+      const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 1023) / 1024, 256);
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, ldsNodes, g_tune, tileW, exs);
+    } else if (plain && g_kernelChoice == 3 && !S.ds.hasNormals) {
+      // two rays per lane, the second parked in LDS: 9 uint4 groups x 64 lanes x 4 waves = 36 KiB per workgroup
+      const size_t ldsBytes = (size_t)kParkBytesPerWave * (256 / 64);
+      const uint32_t blocks = std::min<uint32_t>((cnt + 511) / 512, 256 * 4);
+      hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, true>), dim3(blocks), dim3(256), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, exs);
+    } else if (g_kernelChoice == 4) {
+      // primitive tests pooled across the workgroup (LEAFQ): 17 KiB of LDS per workgroup
+      const bool five = !STATS && g_wavesPerSimd == 5;
+      const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 255) / 256, 256 * 8);
+      if (five)
+        hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, false, 5, true>), dim3(blocks), dim3(256), kLeafQBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, exs);
+      else
+        hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, false, 4, true>), dim3(blocks), dim3(256), kLeafQBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, exs);
+    } else if (!STATS && g_wavesPerSimd == 5) {
+      // 96-VGPR build: 5 waves per SIMD (+4.6 % on the box scene; 6 waves = 80 VGPRs: -15 %, its spills land in LEAF/SHADE)
+      const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 255) / 256, 256 * 8);
+      hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, false, 5>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, exs);
+    } else {
+      const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 255) / 256, 256 * 8);
+      hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, false>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, exs);
+    }
+    if (segmented) hipLaunchKernelGGL(segment_combine_kernel, dim3((cnt + 255) / 256), dim3(256), 0, stream, d_rays, cnt, exs.segments, S.d_segPart, segBase ? 1u : 0u);
   }
 }
 

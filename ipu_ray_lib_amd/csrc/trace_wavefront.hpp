@@ -85,8 +85,11 @@ struct WaveExtras {
   // Segmented pixels (ray_math.h kSegmentSamples): the work atom is (pixel, segment), work index = segment * n + i;
   // every atom leaves its partial rgb sum in segPart[segment][pixel] (segment 0 starts from the incoming rgb) and
   // segment_combine_kernel adds them in segment order afterwards; the last segment writes the hit record.
+  // A launch may cover only the segments [segBase, segBase + segments) of every pixel (the host cuts long renders so
+  // that the partial buffer stays within its budget); segment_combine_kernel then continues the running sum.
   float* segPart = nullptr;      // [segments][n][3]
   uint32_t segments = 1;
+  uint32_t segBase = 0;
 };
 
 template <bool STATS, bool LDS_NODES, int BLOCK, bool TWO_RAYS, int WAVES_PER_SIMD = 4, bool LEAFQ = false>
@@ -122,7 +125,8 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
   const uint32_t tiledCount = tileStreamW ? (n / (8u * tileStreamW)) * (8u * tileStreamW) : 0u;
   const uint32_t numNodes = sc.numNodes;
   const uint32_t spp = ex.sampleCount ? ex.sampleCount : sc.samplesPerPixel;
-  const uint32_t segs = (!TWO_RAYS && ex.segPart) ? ex.segments : 1u;
+  const bool segd = !TWO_RAYS && ex.segPart != nullptr;          // (pixel, segment) work atoms
+  const uint32_t segs = segd ? ex.segments : 1u;
   const uint32_t items = n * segs;                 // (host checks that this fits 32 bits)
 
   // ---- lane state ----
@@ -333,7 +337,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
           // 64 pixels a wave starts with are a compact tile whose primary rays traverse alike. The map is a
           // bijection on [0, n) and any order gives the same image: every pixel owns its RNG stream.
           uint32_t seg = 0, pidx = idx;
-          if (segs > 1) { seg = idx / n; pidx = idx - seg * n; }
+          if (segd) { const uint32_t local = idx / n; pidx = idx - local * n; seg = ex.segBase + local; }
           uint32_t entry = pidx;
           if (tileStreamW && pidx < tiledCount) {
             const uint32_t t = pidx >> 6, within = pidx & 63u, perRow = tileStreamW >> 3;
@@ -606,17 +610,17 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
           else { coldF(3) = coldF(3) + color.x; coldF(4) = coldF(4) + color.y; coldF(5) = coldF(5) + color.z; }
           ++paths;
           ++sample;
-          const bool more = segs > 1 ? ((sample & (kSegmentSamples - 1u)) != 0u && sample < spp) : (sample < spp);
+          const bool more = segd ? ((sample & (kSegmentSamples - 1u)) != 0u && sample < spp) : (sample < spp);
           if (more) ph = PH_GEN;
-          else if (segs > 1 && sample < spp) {
+          else if (segd && sample < spp) {
             // a segment other than the last is complete: its partial sum is all it leaves
-            float* part = ex.segPart + 3 * ((size_t)((sample - 1u) / kSegmentSamples) * n + pixNow);
+            float* part = ex.segPart + 3 * ((size_t)((sample - 1u) / kSegmentSamples - ex.segBase) * n + pixNow);
             part[0] = coldF(3); part[1] = coldF(4); part[2] = coldF(5);
             ph = PH_FETCH;
           } else {
             // pixel complete: rgb sum + the LAST sample's hit record
-            if (segs > 1) {
-              float* part = ex.segPart + 3 * ((size_t)((sample - 1u) / kSegmentSamples) * n + pixNow);
+            if (segd) {
+              float* part = ex.segPart + 3 * ((size_t)((sample - 1u) / kSegmentSamples - ex.segBase) * n + pixNow);
               part[0] = coldF(3); part[1] = coldF(4); part[2] = coldF(5);
             } else
             if (!TWO_RAYS && !ex.slotColor) res->rgb = {coldF(3), coldF(4), coldF(5)};
@@ -715,10 +719,12 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
 }
 
 // rgb of a segmented pixel: ((segment 0, which started from the incoming rgb) + segment 1) + ... in segment order.
-__global__ void __launch_bounds__(256) segment_combine_kernel(mi_trace_result* rays, uint32_t n, uint32_t segments, const float* __restrict__ part) {
+__global__ void __launch_bounds__(256) segment_combine_kernel(mi_trace_result* rays, uint32_t n, uint32_t segments, const float* __restrict__ part, uint32_t continues) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  // the first launch's segment 0 already holds rgb_in + its samples; a later launch continues the running sum
   f3 rgb = mk(part[3 * (size_t)i], part[3 * (size_t)i + 1], part[3 * (size_t)i + 2]);
+  if (continues) { const mi_vec3 acc = rays[i].rgb; rgb = mk(acc.x, acc.y, acc.z) + rgb; }
   for (uint32_t s = 1; s < segments; ++s) {
     const size_t q = 3 * ((size_t)s * n + i);
     rgb = rgb + mk(part[q], part[q + 1], part[q + 2]);

@@ -629,7 +629,7 @@ def test_segmented_pixels_bit_exact(scenes, kernel, monkeypatch):
     rng = np.random.default_rng(3)
     for k in "xyz":
         got["rgb"][k] = rng.random(got.size).astype(np.float32)
-    want = got.copy(); batched = got.copy()
+    want = got.copy(); batched = got.copy(); fresh = got.copy()
     dev.run(got, irl.MODE_PATH_TRACE)
     st = ol.path_trace_pixel_rng(d, want, 16)
     assert_streams_identical(got, want, f"segmented pixels, kernel {kernel}")
@@ -637,6 +637,15 @@ def test_segmented_pixels_bit_exact(scenes, kernel, monkeypatch):
     dev.setRayBatch(1000)
     dev.run(batched, irl.MODE_PATH_TRACE)
     assert_streams_identical(batched, want, f"segmented pixels in batches, kernel {kernel}")
+    # a partial-sum budget too small for all five segments: the render runs as several launches (1 or 2 segments
+    # each; one segment of this frame is 34.5 KB) whose combine passes continue the running sum
+    dev.setRayBatch(0)
+    for kb in ("64", "100"):
+        monkeypatch.setenv("MI_RAYLIB_SEG_BUDGET_KB", kb)
+        cut = fresh.copy()
+        dev.run(cut, irl.MODE_PATH_TRACE)
+        assert_streams_identical(cut, want, f"segmented pixels, {kb} KB of partial sums, kernel {kernel}")
+    monkeypatch.delenv("MI_RAYLIB_SEG_BUDGET_KB")
     dev.close()
     monkeypatch.setenv("MI_RAYLIB_KERNEL", "1")
     irl.IpuScene(d).close()
