@@ -79,7 +79,7 @@ struct mi_scene {
   std::vector<void*> allocations;
   unsigned long long* d_counters = nullptr;
   uint32_t* d_workCounter = nullptr;
-  float* d_segPart = nullptr; size_t segPartFloats = 0;     // partial rgb sums of segmented pixels, [segments][n][3]
+  float* d_segPart[2] = {nullptr, nullptr}; size_t segPartFloats[2] = {0, 0};     // partial rgb sums of segmented pixels, [segments][n][3], one buffer per pipeline slot
   double traceTimeSecs = 0.0;
   float hdriRotationDegrees = 0.f;
   size_t maxNifBatch = 0;
@@ -99,7 +99,7 @@ struct mi_scene {
     if (d_bgr) (void)hipFree(d_bgr);
     if (d_slotColor) (void)hipFree(d_slotColor);
     if (d_slotTp) (void)hipFree(d_slotTp);
-    if (d_segPart) (void)hipFree(d_segPart);
+    for (float* p : d_segPart) if (p) (void)hipFree(p);
     nif.release();
   }
   template <class T> T* keep(T* p) { if (p) allocations.push_back((void*)p); return p; }
@@ -268,9 +268,9 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
   const uint32_t tileW = (!noTiles && w >= 8 && (w % 8) == 0 && cnt >= 8u * w) ? w : 0u;
   const bool plain = ex.rngState == nullptr;      // the sample-at-a-time form only exists for the default kernel
   // Pixels with more than kSegmentSamples samples are traced as (pixel, segment) work atoms (ray_math.h); the two
-  // pipeline slots of mi_render run on different streams, so only slot 0 may use the shared partial-sum buffer and
-  // slot 1 (and the two-rays-per-lane variant, which keeps rgb in memory) falls back to the nested-loop kernel's
-  // in-thread segment loop - the results are the same by definition.
+  // pipeline slots of mi_render run on different streams, so each has its own partial-sum buffer. The
+  // two-rays-per-lane variant, which keeps rgb in memory, falls back to the nested-loop kernel's in-thread
+  // segment loop - the results are the same by definition.
   const uint32_t segments = (S.ds.samplesPerPixel + kSegmentSamples - 1) / kSegmentSamples;
   const bool segmented = plain && segments > 1;
   // One launch covers as many segments of every pixel as the partial-sum budget holds (8 GiB, MI_RAYLIB_SEG_BUDGET_KB
@@ -285,18 +285,18 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
     const uint64_t byIndex = std::max<uint64_t>(1, 0xFFFFFFFFull / cnt);           // work indices are 32-bit
     perLaunch = (uint32_t)std::min<uint64_t>(segments, std::min(byBudget, byIndex));
     const size_t need = (size_t)3 * cnt * perLaunch;
-    if (S.segPartFloats < need) {
-      if (S.d_segPart) (void)hipFree(S.d_segPart);
-      S.d_segPart = nullptr; S.segPartFloats = 0;
-      HIP_CHECK(hipMalloc(&S.d_segPart, need * sizeof(float)));
-      S.segPartFloats = need;
+    if (S.segPartFloats[slot] < need) {
+      if (S.d_segPart[slot]) (void)hipFree(S.d_segPart[slot]);
+      S.d_segPart[slot] = nullptr; S.segPartFloats[slot] = 0;
+      HIP_CHECK(hipMalloc(&S.d_segPart[slot], need * sizeof(float)));
+      S.segPartFloats[slot] = need;
     }
   }
   const uint32_t launches = segmented ? (segments + perLaunch - 1) / perLaunch : 1u;
   for (uint32_t l = 0; l < launches; ++l) {
     const uint32_t segBase = l * perLaunch;
     WaveExtras exs = ex;
-    if (segmented) { exs.segPart = S.d_segPart; exs.segments = std::min(perLaunch, segments - segBase); exs.segBase = segBase; }
+    if (segmented) { exs.segPart = S.d_segPart[slot]; exs.segments = std::min(perLaunch, segments - segBase); exs.segBase = segBase; }
     HIP_CHECK(hipMemsetAsync(workCounter, 0, sizeof(uint32_t), stream));
     const uint64_t items = (uint64_t)cnt * (segmented ? exs.segments : 1u);     // work atoms of this launch
     if (plain && g_kernelChoice == 2 && S.ds.numNodes > 0) {
@@ -329,7 +329,7 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
       const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 255) / 256, 256 * 8);
       hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, false>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, exs);
     }
-    if (segmented) hipLaunchKernelGGL(segment_combine_kernel, dim3((cnt + 255) / 256), dim3(256), 0, stream, d_rays, cnt, exs.segments, S.d_segPart, segBase ? 1u : 0u);
+    if (segmented) hipLaunchKernelGGL(segment_combine_kernel, dim3((cnt + 255) / 256), dim3(256), 0, stream, d_rays, cnt, exs.segments, S.d_segPart[slot], segBase ? 1u : 0u);
   }
 }
 
@@ -344,7 +344,7 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
     else hipLaunchKernelGGL(shadow_trace_kernel<false>, grid, block, 0, stream, S.ds, d_rays, cnt, .05f, light);
   } else if (mode == MI_MODE_PATH_TRACE) {
     const bool segmentedFrame = S.ds.samplesPerPixel > kSegmentSamples;
-    const bool waveOk = !(segmentedFrame && (slot != 0 || g_kernelChoice == 3));     // see launchWavefront
+    const bool waveOk = !(segmentedFrame && g_kernelChoice == 3);     // see launchWavefront
     if (!S.nif.loaded() && g_kernelChoice != 0 && waveOk && S.ds.samplesPerPixel >= 1 && S.ds.maxPathLength >= 1) {
       // sample loop inside the kernel (src/IpuScene.cpp:441), phase-scheduled persistent form
       if (g_fullStats) launchWavefront<true>(S, d_rays, cnt, stream, slot);

@@ -620,7 +620,7 @@ def test_segmented_pixels_bit_exact(scenes, kernel, monkeypatch):
     and partial rgb sum, added in segment order. 300 spp = four full segments + one of 44; the incoming
     rgb is non-zero (segment 0 accumulates onto it). Every kernel variant - the persistent kernel traces (pixel,
     segment) work atoms, the nested-loop kernel loops over the segments in one thread, the two-rays variant falls
-    back to it - must reproduce the oracle bit for bit; so must a batched render (second pipeline slot)."""
+    back to it - must reproduce the oracle bit for bit; so must a batched render (both pipeline slots, each with its own partial-sum buffer)."""
     monkeypatch.setenv("MI_RAYLIB_KERNEL", kernel)
     s = scenes["box"]; d = s.desc
     d.set_image(72, 40); d.samples_per_pixel = 300; d.path_trace = 1
