@@ -1,0 +1,156 @@
+"""Differential campaign: the HIP path against the CPU oracle on seeded random cases, for a time budget.
+
+    python tests/fuzz_parity.py [seconds=240] [seed=1]
+
+Not collected by pytest (run it on a GPU box; it is test infrastructure like the rest of tests/). Every case draws
+a scene (built-in scenes, or a random triangle soup with nasty triangles: zero-area, needle, axis-aligned and
+duplicated/coplanar ones, with or without vertex normals, plus spheres and discs), render parameters (image size
+incl. ragged widths, crop window, 1..150 samples so that 64-sample segments are crossed, seed, jitter, path length,
+roulette depth), a render mode and a kernel variant, renders it with the library and with the oracle, and compares
+every byte of every TraceResult. The first mismatch stops the run with the case's parameters (exit code 1).
+"""
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import ipu_ray_lib_amd as irl  # noqa: E402
+import oracle_lib as ol  # noqa: E402
+
+
+def soup(rng):
+    n_tris = int(rng.integers(8, 900))
+    with_normals = bool(rng.integers(0, 2))
+    centers = rng.uniform(-10, 10, (n_tris, 3)); centers[:, 2] -= 40
+    verts = centers.repeat(3, 0) + rng.normal(scale=float(rng.choice([0.3, 1.5, 6.0])), size=(3 * n_tris, 3))
+    tri = verts.reshape(n_tris, 3, 3)
+    kinds = rng.integers(0, 12, n_tris)
+    for i in np.nonzero(kinds == 0)[0]:                    # zero area: two equal corners
+        tri[i, 2] = tri[i, 1]
+    for i in np.nonzero(kinds == 1)[0]:                    # needle
+        tri[i, 2] = tri[i, 1] + 1e-4 * (tri[i, 0] - tri[i, 1])
+    for i in np.nonzero(kinds == 2)[0]:                    # axis-aligned plane (lies on its bounding box faces)
+        tri[i, :, int(rng.integers(0, 3))] = np.float32(tri[i, 0, int(rng.integers(0, 3))])
+    for i in np.nonzero(kinds == 3)[0]:                    # duplicate of another triangle: exact ties
+        tri[i] = tri[int(rng.integers(0, n_tris))]
+    for i in np.nonzero(kinds == 4)[0]:                    # coplanar overlap with the previous triangle
+        if i:
+            a, b, c = tri[i - 1]
+            tri[i] = [a + 0.1 * (b - a), b, c + 0.2 * (a - c)]
+    verts = tri.reshape(-1, 3).astype(np.float32)
+    half = n_tris // 2
+    tris = np.concatenate([np.arange(3 * half).reshape(-1, 3), np.arange(3 * (n_tris - half)).reshape(-1, 3)]).astype(np.uint16)
+    v = np.zeros(len(verts), dtype=irl.VEC3); v["x"], v["y"], v["z"] = verts[:, 0], verts[:, 1], verts[:, 2]
+    nrm = np.zeros(len(verts) if with_normals else 0, dtype=irl.VEC3)
+    if with_normals:
+        nn = rng.normal(size=(len(verts), 3)); nn /= np.linalg.norm(nn, axis=1, keepdims=True)
+        nrm["x"], nrm["y"], nrm["z"] = nn[:, 0], nn[:, 1], nn[:, 2]
+    info = np.zeros(2, dtype=irl.MESH_INFO)
+    info[0] = (0, 0, half, 3 * half); info[1] = (half, 3 * half, n_tris - half, 3 * (n_tris - half))
+    ns, nd = int(rng.integers(0, 4)), int(rng.integers(0, 3))
+    sph = np.zeros(ns, dtype=irl.SPHERE)
+    for i in range(ns):
+        sph[i] = (*rng.uniform(-8, 8, 2), -40 + rng.uniform(-8, 8), rng.uniform(0.2, 5))
+    dsc = np.zeros(nd, dtype=irl.DISC)
+    for i in range(nd):
+        nv = rng.normal(size=3); nv /= np.linalg.norm(nv)
+        if rng.random() < 0.5:
+            nv = np.eye(3)[int(rng.integers(0, 3))]
+        dsc[i] = (*nv, rng.uniform(2, 30), *rng.uniform(-10, 10, 2), -40 + rng.uniform(-12, 12))
+    n_geom = 2 + ns + nd
+    mats = np.zeros(4, dtype=irl.MATERIAL)
+    for i, (alb, em, ty) in enumerate([((.7, .6, .5), (0, 0, 0), 0), ((.9, .9, .9), (0, 0, 0), 1), ((.8, .9, 1.), (0, 0, 0), 2), ((.5, .5, .5), (3, 2, 1), 0)]):
+        mats[i]["albedo"] = alb; mats[i]["emission"] = em; mats[i]["type"] = ty; mats[i]["ior"] = float(rng.choice([1.0, 1.33, 1.52, 2.4])); mats[i]["emissive"] = int(any(em))
+    mat_ids = rng.integers(0, 4, n_geom).astype(np.uint32)
+    g = irl.SceneDesc()
+    keep = [v, nrm, tris, info, sph, dsc, mats, mat_ids]
+    g.mesh_info, g.num_meshes = info.ctypes.data, 2
+    g.mesh_tris, g.num_tris = tris.ctypes.data, n_tris
+    g.mesh_verts, g.num_verts = v.ctypes.data, len(v)
+    g.mesh_normals, g.num_normals = (nrm.ctypes.data if with_normals else None), len(nrm)
+    g.mat_ids, g.num_mat_ids = mat_ids.ctypes.data, n_geom
+    g.materials, g.num_materials = mats.ctypes.data, 4
+    g.spheres, g.num_spheres = (sph.ctypes.data if ns else None), ns
+    g.discs, g.num_discs = (dsc.ctypes.data if nd else None), nd
+    g.fov_radians = float(rng.uniform(0.3, 1.4))
+    hs = irl.HostScene.from_arrays(g)
+    hs._keep = keep
+    return hs, f"soup({n_tris} tris, normals={with_normals}, {ns} spheres, {nd} discs)"
+
+
+def differing(a, b):
+    ab = a.view(np.uint8).reshape(a.size, -1); bb = b.view(np.uint8).reshape(b.size, -1)
+    return np.nonzero((ab != bb).any(axis=1))[0]
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    threads = os.cpu_count() or 8
+    builtins = {n: irl.HostScene.builtin(n) for n in ("box-simple", "box", "spheres")}
+    t_end = time.time() + budget
+    case = 0
+    rays_total = 0
+    while time.time() < t_end:
+        case += 1
+        if rng.random() < 0.55:
+            s, what = soup(rng)
+        else:
+            name = str(rng.choice(list(builtins))); s, what = builtins[name], name
+        d = s.desc
+        w = int(rng.integers(1, 20)) * 8 + int(rng.integers(0, 2)) * int(rng.integers(1, 8))
+        h = int(rng.integers(1, 16)) * 8 + int(rng.integers(0, 2)) * int(rng.integers(1, 8))
+        crop = None
+        if rng.random() < 0.4:
+            cw, ch = int(rng.integers(1, w + 1)), int(rng.integers(1, h + 1))
+            crop = (cw, ch, int(rng.integers(0, w - cw + 1)), int(rng.integers(0, h - ch + 1)))
+        d.set_image(w, h, crop)
+        spp = int(rng.choice([1, 2, 3, 5, 17, 63, 64, 65, 100, 129, 150])) if rng.random() < 0.5 else int(rng.integers(1, 40))
+        if w * h * spp > 1.2e6:
+            spp = max(1, int(1.2e6 // (w * h)))
+        d.samples_per_pixel = spp
+        d.rng_seed = int(rng.integers(0, 2**63))
+        d.anti_alias_scale = float(rng.choice([0.0, 0.25, 1.0, 3.0]))
+        d.max_path_length = int(rng.integers(0, 14))
+        d.roulette_start_depth = int(rng.integers(0, 7))
+        mode = irl.MODE_PATH_TRACE if rng.random() < 0.8 else irl.MODE_SHADOW_TRACE
+        d.path_trace = 1 if mode == irl.MODE_PATH_TRACE else 0
+        kernel = str(rng.choice(["0", "1", "1", "1", "2", "3", "4"]))
+        waves = str(rng.choice(["4", "5"]))
+        os.environ["MI_RAYLIB_KERNEL"] = kernel; os.environ["MI_RAYLIB_WAVES"] = waves
+        batch = int(rng.integers(1, 4000)) if rng.random() < 0.25 else 0
+        desc = (f"case {case} (seed {seed}): {what} {w}x{h} crop={crop} spp={spp} rngseed={d.rng_seed} aa={d.anti_alias_scale} "
+                f"len={d.max_path_length} roulette={d.roulette_start_depth} mode={mode} kernel={kernel} waves={waves} batch={batch}")
+        dev = irl.IpuScene(d)
+        got = s.init_ray_stream()
+        if rng.random() < 0.3:
+            for k in "xyz":
+                got["rgb"][k] = rng.random(got.size).astype(np.float32)
+        want = got.copy()
+        dev.setRayBatch(batch)
+        dev.run(got, mode)
+        if mode == irl.MODE_PATH_TRACE:
+            ol.path_trace_pixel_rng(d, want, threads)
+        else:
+            ol.shadow_trace(d, want, threads)
+        dev.close()
+        bad = differing(got, want)
+        if bad.size:
+            i = int(bad[0])
+            print(f"MISMATCH {desc}\n {bad.size}/{got.size} TraceResults differ; first at {i}:\n got  {got[i]}\n want {want[i]}", flush=True)
+            sys.exit(1)
+        rays_total += got.size
+        if case % 20 == 0:
+            print(f"{case} cases, {rays_total} TraceResults identical; last: {desc}", flush=True)
+    print(f"OK: {case} cases, {rays_total} TraceResults, all bit-identical to the oracle (seed {seed}, {budget:.0f} s)")
+
+
+if __name__ == "__main__":
+    main()
