@@ -1,6 +1,6 @@
 """Differential campaign: the HIP path against the CPU oracle on seeded random cases, for a time budget.
 
-    python tests/fuzz_parity.py [seconds=240] [seed=1]
+    python tests/fuzz_parity.py [seconds=240] [seed=1] [size_scale=1]
 
 Not collected by pytest (run it on a GPU box; it is test infrastructure like the rest of tests/). Every case draws
 a scene (built-in scenes, or a random triangle soup with nasty triangles: zero-area, needle, axis-aligned and
@@ -92,6 +92,7 @@ def differing(a, b):
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1            # image edges up to 160 x scale pixels
     rng = np.random.default_rng(seed)
     threads = os.cpu_count() or 8
     builtins = {n: irl.HostScene.builtin(n) for n in ("box-simple", "box", "spheres")}
@@ -105,16 +106,16 @@ def main():
         else:
             name = str(rng.choice(list(builtins))); s, what = builtins[name], name
         d = s.desc
-        w = int(rng.integers(1, 20)) * 8 + int(rng.integers(0, 2)) * int(rng.integers(1, 8))
-        h = int(rng.integers(1, 16)) * 8 + int(rng.integers(0, 2)) * int(rng.integers(1, 8))
+        w = int(rng.integers(1, 20 * scale)) * 8 + int(rng.integers(0, 2)) * int(rng.integers(1, 8))
+        h = int(rng.integers(1, 16 * scale)) * 8 + int(rng.integers(0, 2)) * int(rng.integers(1, 8))
         crop = None
         if rng.random() < 0.4:
             cw, ch = int(rng.integers(1, w + 1)), int(rng.integers(1, h + 1))
             crop = (cw, ch, int(rng.integers(0, w - cw + 1)), int(rng.integers(0, h - ch + 1)))
         d.set_image(w, h, crop)
         spp = int(rng.choice([1, 2, 3, 5, 17, 63, 64, 65, 100, 129, 150])) if rng.random() < 0.5 else int(rng.integers(1, 40))
-        if w * h * spp > 1.2e6:
-            spp = max(1, int(1.2e6 // (w * h)))
+        if w * h * spp > 1.2e6 * scale:
+            spp = max(1, int(1.2e6 * scale // (w * h)))
         d.samples_per_pixel = spp
         d.rng_seed = int(rng.integers(0, 2**63))
         d.anti_alias_scale = float(rng.choice([0.0, 0.25, 1.0, 3.0]))
