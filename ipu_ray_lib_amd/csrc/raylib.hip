@@ -469,7 +469,20 @@ int mi_render(mi_scene* scene, int mode, mi_trace_result* rays, size_t n, mi_ray
     const int slots = (numBatches > 1 && !scene->nif.loaded()) ? 2 : 1;
     mi_trace_result* d[2] = {nullptr, nullptr};
     hipStream_t st[2] = {nullptr, nullptr};
-    auto cleanup = [&] { for (int i = 0; i < 2; ++i) { if (d[i]) (void)hipFree(d[i]); if (st[i]) (void)hipStreamDestroy(st[i]); } };
+    // The caller's stream is page-locked for the duration of the call, so the copies are real DMA transfers that
+    // overlap the kernels of the other slot (pageable copies go through a staging buffer and serialise). Memory that
+    // cannot be registered (or MI_RAYLIB_PIN=0) just takes the pageable route.
+    bool pinned = false;
+    {
+      const char* e = getenv("MI_RAYLIB_PIN");
+      if (!(e && e[0] == '0') && n * sizeof(mi_trace_result) >= (size_t)1 << 20)
+        pinned = hipHostRegister(rays, n * sizeof(mi_trace_result), hipHostRegisterDefault) == hipSuccess;
+      if (!pinned) (void)hipGetLastError();
+    }
+    auto cleanup = [&] {
+      for (int i = 0; i < 2; ++i) { if (d[i]) (void)hipFree(d[i]); if (st[i]) (void)hipStreamDestroy(st[i]); }
+      if (pinned) (void)hipHostUnregister(rays);
+    };
     try {
       for (int i = 0; i < slots; ++i) { HIP_CHECK(hipMalloc(&d[i], batch * sizeof(mi_trace_result))); HIP_CHECK(hipStreamCreate(&st[i])); }
       const auto t0 = std::chrono::steady_clock::now();
