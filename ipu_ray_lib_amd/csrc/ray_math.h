@@ -160,11 +160,15 @@ MI_HD uint32_t f2u_sat(float f) {
   return (uint32_t)f;
 }
 // Per-pixel stream: seeded from the user seed and FULL-image (row, col).
-// A pixel's samples are cut into segments of kSegmentSamples; segment j has its own stream (j = 0: the plain
-// per-pixel seed) and its own partial rgb sum, added in segment order. The work atom of the
-// persistent kernel is (pixel, segment): with pixel x all-samples atoms a 1440^2 x 1000 spp frame gives every
-// lane only 6 atoms, and the drain at the end of the frame cost a third of the throughput.
-constexpr uint32_t kSegmentSamples = 64;
+// A pixel's samples are cut into segments of segment_samples(samplesPerPixel); segment j has its own stream
+// (j = 0: the plain per-pixel seed) and its own partial rgb sum, added in segment order. The work
+// atom of the persistent kernel is (pixel, segment): with pixel x all-samples atoms a 1440^2 x 1000 spp frame gives
+// every lane only 6 atoms, and the drain at the end of the frame cost a third of the throughput. The length is a
+// function of the render's sample count alone (never of the batch, crop or GPU count): 64 from 640 spp up (the measured crossover), where
+// the per-atom cost (fetch, seed, partial sum) shows and there are atoms enough; 16 below, where the drain matters
+// more (64 spp: 11.3e9 instead of 9.0e9 casts/s on the 1440^2 box frame; 1000 spp: 13.1e9 instead of 12.8e9).
+constexpr uint32_t kSegmentSamplesLong = 64, kSegmentSamplesShort = 16, kSegmentLongFromSpp = 640;
+MI_HD uint32_t segment_samples(uint32_t samplesPerPixel) { return samplesPerPixel >= kSegmentLongFromSpp ? kSegmentSamplesLong : kSegmentSamplesShort; }
 MI_HD void rng_seed_pixel_segment(Rng& r, uint64_t userSeed, float row, float col, uint32_t segment) {
   const uint64_t pix = ((uint64_t)f2u_sat(row) << 32) | (uint64_t)f2u_sat(col);
   rng_seed(r, (userSeed ^ ((pix + 1ull) * 0x9e3779b97f4a7c15ull)) ^ ((uint64_t)segment * 0xd1b54a32d192ed03ull));

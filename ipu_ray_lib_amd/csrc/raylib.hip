@@ -267,11 +267,12 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
   static const bool noTiles = getenv("MI_RAYLIB_NO_TILES") != nullptr;
   const uint32_t tileW = (!noTiles && w >= 8 && (w % 8) == 0 && cnt >= 8u * w) ? w : 0u;
   const bool plain = ex.rngState == nullptr;      // the sample-at-a-time form only exists for the default kernel
-  // Pixels with more than kSegmentSamples samples are traced as (pixel, segment) work atoms (ray_math.h); the two
+  // Pixels with more than segment_samples(spp) samples are traced as (pixel, segment) work atoms (ray_math.h); the two
   // pipeline slots of mi_render run on different streams, so each has its own partial-sum buffer. The
   // two-rays-per-lane variant, which keeps rgb in memory, falls back to the nested-loop kernel's in-thread
   // segment loop - the results are the same by definition.
-  const uint32_t segments = (S.ds.samplesPerPixel + kSegmentSamples - 1) / kSegmentSamples;
+  const uint32_t segLen = segment_samples(S.ds.samplesPerPixel);
+  const uint32_t segments = (S.ds.samplesPerPixel + segLen - 1) / segLen;
   const bool segmented = plain && segments > 1;
   // One launch covers as many segments of every pixel as the partial-sum budget holds (8 GiB, MI_RAYLIB_SEG_BUDGET_KB
   // overrides; the bench frame needs 0.4 GB); longer renders run as several launches whose combine passes continue
@@ -343,7 +344,7 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
     if (g_fullStats) hipLaunchKernelGGL(shadow_trace_kernel<true>, grid, block, 0, stream, S.ds, d_rays, cnt, .05f, light);
     else hipLaunchKernelGGL(shadow_trace_kernel<false>, grid, block, 0, stream, S.ds, d_rays, cnt, .05f, light);
   } else if (mode == MI_MODE_PATH_TRACE) {
-    const bool segmentedFrame = S.ds.samplesPerPixel > kSegmentSamples;
+    const bool segmentedFrame = S.ds.samplesPerPixel > segment_samples(S.ds.samplesPerPixel);
     const bool waveOk = !(segmentedFrame && g_kernelChoice == 3);     // see launchWavefront
     if (!S.nif.loaded() && g_kernelChoice != 0 && waveOk && S.ds.samplesPerPixel >= 1 && S.ds.maxPathLength >= 1) {
       // sample loop inside the kernel (src/IpuScene.cpp:441), phase-scheduled persistent form

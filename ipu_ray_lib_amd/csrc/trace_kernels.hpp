@@ -334,12 +334,13 @@ __global__ void __launch_bounds__(256) path_trace_kernel(DeviceScene sc, mi_trac
     PathState ps;
     ps.flags = 0; ps.primID = MI_INVALID_PRIM; ps.geomID = MI_INVALID_GEOM; ps.tMax = kInf;
     ps.o = mk(0, 0, 0); ps.d = mk(0, 0, -1); ps.n = mk(0, 0, 1); ps.tp = mk(1, 1, 1);
-    f3 total = rgb;                          // segments (ray_math.h, kSegmentSamples): sum of the finished ones
+    f3 total = rgb;                          // segments (ray_math.h, segment_samples): sum of the finished ones
+    const uint32_t segLen = segment_samples(numSamples);
     const bool segmented = rngStates == nullptr;       // the sample-at-a-time form (NIF) keeps one stream per pixel
     for (uint32_t s = 0; s < numSamples; ++s) {
-      if (segmented && s != 0 && (s % kSegmentSamples) == 0) {
+      if (segmented && s != 0 && (s % segLen) == 0) {
         // a new segment: own stream, own partial sum; segment 0 accumulates onto the incoming rgb directly
-        const uint32_t segment = s / kSegmentSamples;
+        const uint32_t segment = s / segLen;
         if (segment > 1) total = total + rgb; else total = rgb;
         rgb = mk(0.f, 0.f, 0.f);
         rng_seed_pixel_segment(rng, sc.rngSeed, prow, pcol, segment);
@@ -400,7 +401,7 @@ __global__ void __launch_bounds__(256) path_trace_kernel(DeviceScene sc, mi_trac
       ++paths;
     }
     if (rngStates) rngStates[idx] = rng;
-    if (segmented && numSamples > kSegmentSamples) rgb = total + rgb;     // + the last segment's partial sum
+    if (segmented && numSamples > segLen) rgb = total + rgb;     // + the last segment's partial sum
     if (numSamples) {
       res->rgb = {rgb.x, rgb.y, rgb.z};
       mi_hit_record hr;

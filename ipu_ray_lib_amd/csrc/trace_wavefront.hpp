@@ -10,7 +10,7 @@
 //     FETCH work unit finished: write it back, take another one from the global work counter
 // and each loop iteration the wave votes (ballot + popcount, scalar) and runs the phase most of its
 // lanes are waiting in. A lane that finishes a path immediately starts its next sample, a lane that
-// finishes a work unit - a pixel, or a 64-sample segment of one (ray_math.h) - pulls a new one, so no lane
+// finishes a work unit - a pixel, or a 16- or 64-sample segment of one (ray_math.h) - pulls a new one, so no lane
 // idles until the frame runs out of work; units are small on purpose, the drain at the end of a frame is paid
 // per unit. The kernel is bound by the latency of each wave's dependent chain (node load -> box test -> vote),
 // so the scheduling below is about few, short chains: several box tests per vote, whole 8x8 tiles per wave,
@@ -82,7 +82,7 @@ struct WaveExtras {
   uint32_t* index = nullptr; uint32_t* count = nullptr;
   float azimuthRotation = 0.f;
   uint32_t fetchChunk = 0;       // work indices taken per global atomic (multiple of 64; 0 = 64)
-  // Segmented pixels (ray_math.h kSegmentSamples): the work atom is (pixel, segment), work index = segment * n + i;
+  // Segmented pixels (ray_math.h segment_samples): the work atom is (pixel, segment), work index = segment * n + i;
   // every atom leaves its partial rgb sum in segPart[segment][pixel] (segment 0 starts from the incoming rgb) and
   // segment_combine_kernel adds them in segment order afterwards; the last segment writes the hit record.
   // A launch may cover only the segments [segBase, segBase + segments) of every pixel (the host cuts long renders so
@@ -126,6 +126,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
   const uint32_t numNodes = sc.numNodes;
   const uint32_t spp = ex.sampleCount ? ex.sampleCount : sc.samplesPerPixel;
   const bool segd = !TWO_RAYS && ex.segPart != nullptr;          // (pixel, segment) work atoms
+  const uint32_t segShift = segment_samples(spp) == kSegmentSamplesLong ? 6u : 4u, segMask = (1u << segShift) - 1u;
   const uint32_t segs = segd ? ex.segments : 1u;
   const uint32_t items = n * segs;                 // (host checks that this fits 32 bits)
 
@@ -353,7 +354,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
           }
           if (ex.rngState && !ex.seedNow) rng = ex.rngState[entry];
           else rng_seed_pixel_segment(rng, sc.rngSeed, prow, pcol, seg);
-          sample = seg * kSegmentSamples;
+          sample = seg << segShift;
           pathStore();                 // (GEN initialises the rest)
           ph = PH_GEN;
         } else {
@@ -610,17 +611,17 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
           else { coldF(3) = coldF(3) + color.x; coldF(4) = coldF(4) + color.y; coldF(5) = coldF(5) + color.z; }
           ++paths;
           ++sample;
-          const bool more = segd ? ((sample & (kSegmentSamples - 1u)) != 0u && sample < spp) : (sample < spp);
+          const bool more = segd ? ((sample & segMask) != 0u && sample < spp) : (sample < spp);
           if (more) ph = PH_GEN;
           else if (segd && sample < spp) {
             // a segment other than the last is complete: its partial sum is all it leaves
-            float* part = ex.segPart + 3 * ((size_t)((sample - 1u) / kSegmentSamples - ex.segBase) * n + pixNow);
+            float* part = ex.segPart + 3 * ((size_t)(((sample - 1u) >> segShift) - ex.segBase) * n + pixNow);
             part[0] = coldF(3); part[1] = coldF(4); part[2] = coldF(5);
             ph = PH_FETCH;
           } else {
             // pixel complete: rgb sum + the LAST sample's hit record
             if (segd) {
-              float* part = ex.segPart + 3 * ((size_t)((sample - 1u) / kSegmentSamples - ex.segBase) * n + pixNow);
+              float* part = ex.segPart + 3 * ((size_t)(((sample - 1u) >> segShift) - ex.segBase) * n + pixNow);
               part[0] = coldF(3); part[1] = coldF(4); part[2] = coldF(5);
             } else
             if (!TWO_RAYS && !ex.slotColor) res->rgb = {coldF(3), coldF(4), coldF(5)};

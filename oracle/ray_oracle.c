@@ -737,11 +737,12 @@ static uint32_t f2u_sat(float f) {
 /* Per-pixel stream seed: one xoroshiro128** state per image pixel, derived
  * from the user seed and the pixel's (row, col) in FULL-image coordinates, so the image does
  * not depend on crop windows, batch sizes or the number of GPUs. */
-/* Tier-1 stream definition: a pixel's samples are cut into SEGMENTS of O_SEGMENT_SAMPLES; segment j
- * has its own stream, seeded from (seed, row, col, j) - j = 0 is the plain per-pixel seed - and its own partial
- * rgb sum; the pixel's rgb is ((rgb_in + segment 0) + segment 1) + ... in segment order, segment 0 accumulating
- * onto rgb_in directly. For samplesPerPixel <= O_SEGMENT_SAMPLES this is one stream and one running sum. */
-#define O_SEGMENT_SAMPLES 64u
+/* Tier-1 stream definition: a pixel's samples are cut into SEGMENTS of o_segment_samples(spp) - 64
+ * samples from 640 spp up, 16 below, a function of the render's sample count alone; segment j has its own stream,
+ * seeded from (seed, row, col, j) - j = 0 is the plain per-pixel seed - and its own partial rgb sum; the pixel's rgb
+ * is ((rgb_in + segment 0) + segment 1) + ... in segment order, segment 0 accumulating onto rgb_in directly. Up to
+ * one segment's worth of samples this is one stream and one running sum. */
+static uint32_t o_segment_samples(uint32_t samplesPerPixel) { return samplesPerPixel >= 640u ? 64u : 16u; }
 static void pixel_stream_seed_segment(uint64_t s[2], uint64_t rngSeed, float pu, float pv, uint32_t segment) {
   const uint64_t pix = ((uint64_t)f2u_sat(pu) << 32) | (uint64_t)f2u_sat(pv);
   o_xoshiro_seed(s, (rngSeed ^ ((pix + 1ull) * 0x9e3779b97f4a7c15ull)) ^ ((uint64_t)segment * 0xd1b54a32d192ed03ull));
@@ -772,8 +773,9 @@ void o_path_trace_pixel_rng(const oscene* sc, otrace* rays, size_t n, int numThr
       otrace* r = &rays[i];
       uint64_t s[2];
       uint32_t segment = 0;
-      for (uint32_t first = 0; first < sc->samplesPerPixel || first == 0; first += O_SEGMENT_SAMPLES, ++segment) {
-        const uint32_t last = sc->samplesPerPixel - first < O_SEGMENT_SAMPLES ? sc->samplesPerPixel : first + O_SEGMENT_SAMPLES;
+      const uint32_t segLen = o_segment_samples(sc->samplesPerPixel);
+      for (uint32_t first = 0; first < sc->samplesPerPixel || first == 0; first += segLen, ++segment) {
+        const uint32_t last = sc->samplesPerPixel - first < segLen ? sc->samplesPerPixel : first + segLen;
         pixel_stream_seed_segment(s, sc->rngSeed, r->u, r->v, segment);
         const ovec3 total = r->rgb;
         if (segment > 0) r->rgb = V(0.f, 0.f, 0.f);

@@ -5,7 +5,7 @@
 Not collected by pytest (run it on a GPU box; it is test infrastructure like the rest of tests/). Every case draws
 a scene (built-in scenes, or a random triangle soup with nasty triangles: zero-area, needle, axis-aligned and
 duplicated/coplanar ones, with or without vertex normals, plus spheres and discs), render parameters (image size
-incl. ragged widths, crop window, 1..150 samples so that 64-sample segments are crossed, seed, jitter, path length,
+incl. ragged widths, crop window, 1..900 samples so that both segment lengths and their boundaries are crossed, seed, jitter, path length,
 roulette depth), a render mode and a kernel variant, renders it with the library and with the oracle, and compares
 every byte of every TraceResult. The first mismatch stops the run with the case's parameters (exit code 1).
 """
@@ -113,7 +113,7 @@ def main():
             cw, ch = int(rng.integers(1, w + 1)), int(rng.integers(1, h + 1))
             crop = (cw, ch, int(rng.integers(0, w - cw + 1)), int(rng.integers(0, h - ch + 1)))
         d.set_image(w, h, crop)
-        spp = int(rng.choice([1, 2, 3, 5, 17, 63, 64, 65, 100, 129, 150])) if rng.random() < 0.5 else int(rng.integers(1, 40))
+        spp = int(rng.choice([1, 2, 3, 5, 15, 16, 17, 31, 33, 64, 65, 150, 511, 639, 640, 641, 705, 900])) if rng.random() < 0.5 else int(rng.integers(1, 40))
         if w * h * spp > 1.2e6 * scale:
             spp = max(1, int(1.2e6 * scale // (w * h)))
         d.samples_per_pixel = spp

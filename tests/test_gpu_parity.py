@@ -614,16 +614,17 @@ def test_randomised_render_parameters_against_oracle(scenes):
         d.set_image(96, 64); d.anti_alias_scale = 0.25; d.max_path_length = 10; d.roulette_start_depth = 3; d.rng_seed = 1442
 
 
-@pytest.mark.parametrize("kernel", ["0", "1", "2", "3", "4"])
-def test_segmented_pixels_bit_exact(scenes, kernel, monkeypatch):
-    """More than 64 samples per pixel: the pixel is traced as segments of 64 samples, each with its own RNG stream
-    and partial rgb sum, added in segment order. 300 spp = four full segments + one of 44; the incoming
+@pytest.mark.parametrize("kernel,spp", [("0", 300), ("1", 300), ("2", 300), ("3", 300), ("4", 300), ("0", 700), ("1", 700), ("3", 700)])
+def test_segmented_pixels_bit_exact(scenes, kernel, spp, monkeypatch):
+    """More samples per pixel than one segment holds: the pixel is traced as segments (16 samples below 640 spp, 64
+    from 640 spp up), each with its own RNG stream and partial rgb sum, added in segment order.
+    300 spp = eighteen full short segments + one of 12; 700 spp = ten full long segments + one of 60; the incoming
     rgb is non-zero (segment 0 accumulates onto it). Every kernel variant - the persistent kernel traces (pixel,
     segment) work atoms, the nested-loop kernel loops over the segments in one thread, the two-rays variant falls
     back to it - must reproduce the oracle bit for bit; so must a batched render (both pipeline slots, each with its own partial-sum buffer)."""
     monkeypatch.setenv("MI_RAYLIB_KERNEL", kernel)
     s = scenes["box"]; d = s.desc
-    d.set_image(72, 40); d.samples_per_pixel = 300; d.path_trace = 1
+    d.set_image(72, 40); d.samples_per_pixel = spp; d.path_trace = 1
     dev = irl.IpuScene(d)
     got = s.init_ray_stream()
     rng = np.random.default_rng(3)
@@ -637,7 +638,7 @@ def test_segmented_pixels_bit_exact(scenes, kernel, monkeypatch):
     dev.setRayBatch(1000)
     dev.run(batched, irl.MODE_PATH_TRACE)
     assert_streams_identical(batched, want, f"segmented pixels in batches, kernel {kernel}")
-    # a partial-sum budget too small for all five segments: the render runs as several launches (1 or 2 segments
+    # a partial-sum budget too small for all the segments: the render runs as several launches (1 or 2 segments
     # each; one segment of this frame is 34.5 KB) whose combine passes continue the running sum
     dev.setRayBatch(0)
     for kb in ("64", "100"):
