@@ -434,22 +434,44 @@ inline void nif_launch_mlp(const NifDevice& nif, const float* u, const float* v,
 
 // Replays the reference's per-sample order for one launch of `samples` slots per pixel (trace_wavefront.hpp,
 // WaveExtras): rgb += color of the sample's path (codelets/TraceCodelets.cpp:262), then, if it escaped,
-// rgb += throughput * env with BGR -> RGB (PostProcessEscapedRays, codelets :361-382).
-__global__ void __launch_bounds__(256) nif_accumulate_kernel(mi_trace_result* rays, uint32_t n, uint32_t samples, const float* __restrict__ color,
-                                                             const float* __restrict__ tp, const float* __restrict__ u, const float* __restrict__ bgr) {
+// rgb += throughput * env with BGR -> RGB (PostProcessEscapedRays, codelets :361-382) - within each segment of
+// 2^segShift samples; the segments' partial sums are added in segment order, the render's segment 0 accumulating
+// onto the incoming rgb directly (ray_math.h segment_samples; a launch starts at a segment boundary).
+__global__ void __launch_bounds__(256) nif_accumulate_kernel(mi_trace_result* rays, uint32_t n, uint32_t samples, uint32_t segShift, uint32_t firstSegment,
+                                                             const float* __restrict__ color, const float* __restrict__ tp, const float* __restrict__ u,
+                                                             const float* __restrict__ bgr) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  mi_vec3 rgb = rays[i].rgb;
-  for (uint32_t s = 0; s < samples; ++s) {
-    const size_t q = (size_t)s * n + i;
-    rgb.x += color[3 * q]; rgb.y += color[3 * q + 1]; rgb.z += color[3 * q + 2];
-    if (u[q] >= 0.f) {
-      rgb.x += tp[3 * q] * bgr[3 * q + 2];
-      rgb.y += tp[3 * q + 1] * bgr[3 * q + 1];
-      rgb.z += tp[3 * q + 2] * bgr[3 * q];
+  mi_vec3 total = rays[i].rgb;
+  for (uint32_t s0 = 0; s0 < samples; s0 += 1u << segShift) {
+    const bool first = firstSegment == 0 && s0 == 0;
+    mi_vec3 rgb = first ? total : mi_vec3{0.f, 0.f, 0.f};
+    const uint32_t s1 = min(samples, s0 + (1u << segShift));
+    for (uint32_t s = s0; s < s1; ++s) {
+      const size_t q = (size_t)s * n + i;
+      rgb.x += color[3 * q]; rgb.y += color[3 * q + 1]; rgb.z += color[3 * q + 2];
+      if (u[q] >= 0.f) {
+        rgb.x += tp[3 * q] * bgr[3 * q + 2];
+        rgb.y += tp[3 * q + 1] * bgr[3 * q + 1];
+        rgb.z += tp[3 * q + 2] * bgr[3 * q];
+      }
     }
+    if (first) total = rgb; else { total.x += rgb.x; total.y += rgb.y; total.z += rgb.z; }
   }
-  rays[i].rgb = rgb;
+  rays[i].rgb = total;
+}
+
+// Sample-at-a-time NIF renders: at a segment boundary the finished segments' sum moves to `total` and rgb restarts
+// from zero (segment 0 had started from the incoming rgb); `finish` adds the last segment's partial sum back.
+__global__ void __launch_bounds__(256) nif_segment_roll_kernel(mi_trace_result* rays, float* __restrict__ total, uint32_t n, uint32_t segment, uint32_t finish) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const mi_vec3 rgb = rays[i].rgb;
+  mi_vec3 t = rgb;
+  if (segment > 1 || finish) { t.x = total[3 * i] + rgb.x; t.y = total[3 * i + 1] + rgb.y; t.z = total[3 * i + 2] + rgb.z; }
+  if (finish) { rays[i].rgb = t; return; }
+  total[3 * i] = t.x; total[3 * i + 1] = t.y; total[3 * i + 2] = t.z;
+  rays[i].rgb = {0.f, 0.f, 0.f};
 }
 
 // mi_nif_infer_device: every row is evaluated (no compaction)

@@ -88,7 +88,9 @@ struct mi_scene {
   // scratch for the per-sample NIF loop
   Rng* d_rng = nullptr; float* d_u = nullptr; float* d_v = nullptr; float* d_bgr = nullptr; size_t scratchRays = 0;
   float* d_slotColor = nullptr; float* d_slotTp = nullptr;   // NIF renders: per-(sample, pixel) slots of one launch
+  float* d_segTotal = nullptr;                                // sample-at-a-time NIF renders: sum of the finished segments, [n][3]
   uint32_t scratchSamples = 0;                                // samples per launch the slot buffers are sized for
+  uint32_t scratchAsked = 0;                                  // the MI_RAYLIB_NIF_SPL value they were sized under (0 = default)
 
   ~mi_scene() {
     (void)hipSetDevice(device);
@@ -99,6 +101,7 @@ struct mi_scene {
     if (d_bgr) (void)hipFree(d_bgr);
     if (d_slotColor) (void)hipFree(d_slotColor);
     if (d_slotTp) (void)hipFree(d_slotTp);
+    if (d_segTotal) (void)hipFree(d_segTotal);
     for (float* p : d_segPart) if (p) (void)hipFree(p);
     nif.release();
   }
@@ -224,13 +227,23 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
   S.keep(S.d_workCounter);
 }
 
-  // slots per pixel per launch in NIF renders (44 B each, default 32); MI_RAYLIB_NIF_SPL overrides (1..64)
-
+// Slots per pixel per launch in NIF renders (44 B each). A launch holds whole segments (ray_math.h segment_samples);
+// more samples per launch mean more (pixel, segment) atoms per lane and fewer launch tails: 128 by default, fewer
+// when n x samples x 44 B would pass 16 GiB (never less than one segment). MI_RAYLIB_NIF_SPL overrides (1..128,
+// rounded up to whole segments).
 void ensureScratch(mi_scene& S, size_t n) {
   {
     const char* e = getenv("MI_RAYLIB_NIF_SPL");
-    uint32_t v = e ? (uint32_t)atoi(e) : 32u;
-    if (v < 1 || v > 64) v = 32u;
+    const uint32_t asked = e ? (uint32_t)atoi(e) : 0u;
+    const uint32_t segLen = segment_samples(S.ds.samplesPerPixel);
+    uint32_t v = (asked >= 1 && asked <= 128) ? asked : 128u;
+    v = ((v + segLen - 1) / segLen) * segLen;
+    v = std::min(v, std::max(segLen, ((S.ds.samplesPerPixel + segLen - 1) / segLen) * segLen));      // no more than the render has
+    if (!(asked >= 1 && asked <= 128))
+      while (v > segLen && (uint64_t)n * v * 44u > ((uint64_t)16 << 30)) v -= segLen;
+    // keep what is there when it still fits this stream and the request has not changed
+    if (S.scratchRays >= n && S.scratchAsked == asked && S.scratchSamples >= segLen && S.scratchSamples % segLen == 0) return;
+    S.scratchAsked = asked;
     if (v != S.scratchSamples) { S.scratchSamples = v; S.scratchRays = 0; }     // slot buffers are sized for n x v
   }
   if (S.scratchRays >= n) return;
@@ -240,7 +253,8 @@ void ensureScratch(mi_scene& S, size_t n) {
   if (S.d_bgr) (void)hipFree(S.d_bgr);
   if (S.d_slotColor) (void)hipFree(S.d_slotColor);
   if (S.d_slotTp) (void)hipFree(S.d_slotTp);
-  S.d_rng = nullptr; S.d_u = S.d_v = S.d_bgr = S.d_slotColor = S.d_slotTp = nullptr; S.scratchRays = 0;
+  if (S.d_segTotal) (void)hipFree(S.d_segTotal);
+  S.d_rng = nullptr; S.d_u = S.d_v = S.d_bgr = S.d_slotColor = S.d_slotTp = S.d_segTotal = nullptr; S.scratchRays = 0;
   const size_t slots = n * S.scratchSamples;
   HIP_CHECK(hipMalloc(&S.d_rng, n * sizeof(Rng)));
   HIP_CHECK(hipMalloc(&S.d_u, slots * sizeof(float)));
@@ -248,6 +262,7 @@ void ensureScratch(mi_scene& S, size_t n) {
   HIP_CHECK(hipMalloc(&S.d_bgr, 3 * slots * sizeof(float)));
   HIP_CHECK(hipMalloc(&S.d_slotColor, 3 * slots * sizeof(float)));
   HIP_CHECK(hipMalloc(&S.d_slotTp, 3 * slots * sizeof(float)));
+  HIP_CHECK(hipMalloc(&S.d_segTotal, 3 * n * sizeof(float)));
   S.scratchRays = n;
 }
 
@@ -266,7 +281,7 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
   const uint32_t w = (uint32_t)S.params.window_w;
   static const bool noTiles = getenv("MI_RAYLIB_NO_TILES") != nullptr;
   const uint32_t tileW = (!noTiles && w >= 8 && (w % 8) == 0 && cnt >= 8u * w) ? w : 0u;
-  const bool plain = ex.rngState == nullptr;      // the sample-at-a-time form only exists for the default kernel
+  const bool plain = ex.slotColor == nullptr;      // NIF launches (slots) only exist for the default kernel
   // Pixels with more than segment_samples(spp) samples are traced as (pixel, segment) work atoms (ray_math.h); the two
   // pipeline slots of mi_render run on different streams, so each has its own partial-sum buffer. The
   // two-rays-per-lane variant, which keeps rgb in memory, falls back to the nested-loop kernel's in-thread
@@ -299,7 +314,7 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
     WaveExtras exs = ex;
     if (segmented) { exs.segPart = S.d_segPart[slot]; exs.segments = std::min(perLaunch, segments - segBase); exs.segBase = segBase; }
     HIP_CHECK(hipMemsetAsync(workCounter, 0, sizeof(uint32_t), stream));
-    const uint64_t items = (uint64_t)cnt * (segmented ? exs.segments : 1u);     // work atoms of this launch
+    const uint64_t items = (uint64_t)cnt * ((segmented || !plain) ? exs.segments : 1u);     // work atoms of this launch
     if (plain && g_kernelChoice == 2 && S.ds.numNodes > 0) {
       // one 1024-thread workgroup per CU shares one LDS copy of the first nodes of the (preorder) array
       const uint32_t ldsNodes = std::min<uint32_t>(S.ds.numNodes, kLdsBudgetBytes / (uint32_t)sizeof(GNode));
@@ -364,24 +379,29 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
         // MLP runs on the compacted escaped slots, and a per-pixel pass adds everything in the reference's order
         if ((uint64_t)cnt * S.scratchSamples > 0xFFFFFFFFull) throw ArgError("mi_render: ray batch too large for a NIF render (cut it with mi_scene_set_ray_batch)");
         S.nif.ensureIndex((size_t)cnt * S.scratchSamples);
+        const uint32_t segLen = segment_samples(S.ds.samplesPerPixel), segShift = segLen == kSegmentSamplesLong ? 6u : 4u;
         for (uint32_t s0 = 0; s0 < S.ds.samplesPerPixel; s0 += S.scratchSamples) {
           const uint32_t sc = std::min<uint32_t>(S.scratchSamples, S.ds.samplesPerPixel - s0);
           HIP_CHECK(hipMemsetAsync(S.nif.d_count, 0, sizeof(uint32_t), stream));
           WaveExtras ex;
-          ex.rngState = S.d_rng; ex.seedNow = (s0 == 0) ? 1u : 0u; ex.sampleCount = sc;
+          ex.sampleCount = sc; ex.segments = (sc + segLen - 1) / segLen; ex.segBase = s0 / segLen;     // (pixel, segment) atoms
           ex.u = S.d_u; ex.v = S.d_v; ex.slotColor = S.d_slotColor; ex.slotTp = S.d_slotTp;
           ex.index = S.nif.d_index; ex.count = S.nif.d_count; ex.azimuthRotation = radians;
           if (g_fullStats) launchWavefront<true>(S, d_rays, cnt, stream, slot, ex);
           else launchWavefront<false>(S, d_rays, cnt, stream, slot, ex);
           nif_launch_mlp(S.nif, S.d_u, S.d_v, S.nif.d_index, S.nif.d_count, cnt * sc, S.d_bgr, nullptr, stream, true);
-          hipLaunchKernelGGL(nif_accumulate_kernel, grid, block, 0, stream, d_rays, cnt, sc, S.d_slotColor, S.d_slotTp, S.d_u, S.d_bgr);
+          hipLaunchKernelGGL(nif_accumulate_kernel, grid, block, 0, stream, d_rays, cnt, sc, segShift, ex.segBase, S.d_slotColor, S.d_slotTp, S.d_u, S.d_bgr);
         }
       } else {
+        const uint32_t segLen = segment_samples(S.ds.samplesPerPixel);
         for (uint32_t s = 0; s < S.ds.samplesPerPixel; ++s) {
+          // a new segment: the finished ones move to the running total, rgb restarts from zero
+          if (s != 0 && s % segLen == 0) hipLaunchKernelGGL(nif_segment_roll_kernel, grid, block, 0, stream, d_rays, S.d_segTotal, cnt, s / segLen, 0u);
           if (g_fullStats) hipLaunchKernelGGL(path_trace_kernel<true>, grid, block, 0, stream, S.ds, d_rays, cnt, s, 1u, S.d_rng);
           else hipLaunchKernelGGL(path_trace_kernel<false>, grid, block, 0, stream, S.ds, d_rays, cnt, s, 1u, S.d_rng);
           nif_env_pass(S.nif, d_rays, cnt, radians, S.d_u, S.d_v, S.d_bgr, S.maxNifBatch, stream);
         }
+        if (S.ds.samplesPerPixel > segLen) hipLaunchKernelGGL(nif_segment_roll_kernel, grid, block, 0, stream, d_rays, S.d_segTotal, cnt, 0u, 1u);
       }
     }
   } else {

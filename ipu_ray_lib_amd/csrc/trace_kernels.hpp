@@ -328,15 +328,18 @@ __global__ void __launch_bounds__(256) path_trace_kernel(DeviceScene sc, mi_trac
     mi_trace_result* res = rays + idx;
     const float prow = res->u, pcol = res->v;
     Rng rng;
-    if (rngStates && firstSample != 0) rng = rngStates[idx];
-    else rng_seed_pixel(rng, sc.rngSeed, prow, pcol);
+    // sample-at-a-time form (NIF renders): the stream lives in rngStates between launches and is re-seeded at
+    // every segment boundary of the render (the host rolls the partial sums there, nif_segment_roll_kernel)
+    const uint32_t segLenRender = segment_samples(sc.samplesPerPixel);
+    if (rngStates && (firstSample % segLenRender) != 0) rng = rngStates[idx];
+    else rng_seed_pixel_segment(rng, sc.rngSeed, prow, pcol, rngStates ? firstSample / segLenRender : 0u);
     f3 rgb = mk(res->rgb.x, res->rgb.y, res->rgb.z);
     PathState ps;
     ps.flags = 0; ps.primID = MI_INVALID_PRIM; ps.geomID = MI_INVALID_GEOM; ps.tMax = kInf;
     ps.o = mk(0, 0, 0); ps.d = mk(0, 0, -1); ps.n = mk(0, 0, 1); ps.tp = mk(1, 1, 1);
     f3 total = rgb;                          // segments (ray_math.h, segment_samples): sum of the finished ones
     const uint32_t segLen = segment_samples(numSamples);
-    const bool segmented = rngStates == nullptr;       // the sample-at-a-time form (NIF) keeps one stream per pixel
+    const bool segmented = rngStates == nullptr;       // (the sample-at-a-time form is one sample per launch: the host rolls its segments)
     for (uint32_t s = 0; s < numSamples; ++s) {
       if (segmented && s != 0 && (s % segLen) == 0) {
         // a new segment: own stream, own partial sum; segment 0 accumulates onto the incoming rgb directly

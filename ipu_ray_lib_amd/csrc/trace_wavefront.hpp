@@ -71,12 +71,11 @@ struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, tradeAt, qPush 
 // its radiance `color`, and - if it escaped - throughput and environment coordinates (PreProcessEscapedRays,
 // codelets/TraceCodelets.cpp:321-358; u = -1 marks "did not escape") plus q appended to the compacted list the
 // MLP consumes. A per-pixel pass then replays the reference's order exactly: for each sample rgb += color, then
-// rgb += throughput * env (nif_accumulate_kernel). The per-pixel RNG streams persist in rngState between launches.
+// rgb += throughput * env, segment by segment (nif_accumulate_kernel). A launch holds whole segments, each its own
+// work atom and RNG stream, so no generator state is carried from launch to launch.
 // All-null extras = the plain multi-sample launch (rgb accumulated in registers).
 struct WaveExtras {
-  Rng* rngState = nullptr;       // [n] per ray; loaded at FETCH unless seedNow, stored when the launch's samples are done
-  uint32_t seedNow = 1;
-  uint32_t sampleCount = 0;      // 0 = scene's samplesPerPixel
+  uint32_t sampleCount = 0;      // samples of this launch (whole segments, except at the end of the render); 0 = scene's samplesPerPixel
   float* u = nullptr; float* v = nullptr;          // [sampleCount][n]
   float* slotColor = nullptr; float* slotTp = nullptr;   // [sampleCount][n][3]
   uint32_t* index = nullptr; uint32_t* count = nullptr;
@@ -87,6 +86,8 @@ struct WaveExtras {
   // segment_combine_kernel adds them in segment order afterwards; the last segment writes the hit record.
   // A launch may cover only the segments [segBase, segBase + segments) of every pixel (the host cuts long renders so
   // that the partial buffer stays within its budget); segment_combine_kernel then continues the running sum.
+  // NIF launches use the same atoms (segments/segBase describe the launch's samples; slots instead of partial sums):
+  // every atom seeds its own segment stream, so nothing but the slots is carried from launch to launch.
   float* segPart = nullptr;      // [segments][n][3]
   uint32_t segments = 1;
   uint32_t segBase = 0;
@@ -125,8 +126,8 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
   const uint32_t tiledCount = tileStreamW ? (n / (8u * tileStreamW)) * (8u * tileStreamW) : 0u;
   const uint32_t numNodes = sc.numNodes;
   const uint32_t spp = ex.sampleCount ? ex.sampleCount : sc.samplesPerPixel;
-  const bool segd = !TWO_RAYS && ex.segPart != nullptr;          // (pixel, segment) work atoms
-  const uint32_t segShift = segment_samples(spp) == kSegmentSamplesLong ? 6u : 4u, segMask = (1u << segShift) - 1u;
+  const bool segd = !TWO_RAYS && (ex.segPart != nullptr || ex.slotColor != nullptr);          // (pixel, segment) work atoms
+  const uint32_t segShift = segment_samples(sc.samplesPerPixel) == kSegmentSamplesLong ? 6u : 4u, segMask = (1u << segShift) - 1u;
   const uint32_t segs = segd ? ex.segments : 1u;
   const uint32_t items = n * segs;                 // (host checks that this fits 32 bits)
 
@@ -352,9 +353,8 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
             if (seg == 0) { coldF(3) = res->rgb.x; coldF(4) = res->rgb.y; coldF(5) = res->rgb.z; }
             else { coldF(3) = 0.f; coldF(4) = 0.f; coldF(5) = 0.f; }           // a later segment's own partial sum
           }
-          if (ex.rngState && !ex.seedNow) rng = ex.rngState[entry];
-          else rng_seed_pixel_segment(rng, sc.rngSeed, prow, pcol, seg);
-          sample = seg << segShift;
+          rng_seed_pixel_segment(rng, sc.rngSeed, prow, pcol, seg);
+          sample = (ex.slotColor ? seg - ex.segBase : seg) << segShift;      // slots are numbered within the launch
           pathStore();                 // (GEN initialises the rest)
           ph = PH_GEN;
         } else {
@@ -614,13 +614,15 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
           const bool more = segd ? ((sample & segMask) != 0u && sample < spp) : (sample < spp);
           if (more) ph = PH_GEN;
           else if (segd && sample < spp) {
-            // a segment other than the last is complete: its partial sum is all it leaves
-            float* part = ex.segPart + 3 * ((size_t)(((sample - 1u) >> segShift) - ex.segBase) * n + pixNow);
-            part[0] = coldF(3); part[1] = coldF(4); part[2] = coldF(5);
+            // a segment other than the last is complete: its partial sum (or its slots) is all it leaves
+            if (ex.segPart) {
+              float* part = ex.segPart + 3 * ((size_t)(((sample - 1u) >> segShift) - ex.segBase) * n + pixNow);
+              part[0] = coldF(3); part[1] = coldF(4); part[2] = coldF(5);
+            }
             ph = PH_FETCH;
           } else {
             // pixel complete: rgb sum + the LAST sample's hit record
-            if (segd) {
+            if (ex.segPart && !TWO_RAYS) {
               float* part = ex.segPart + 3 * ((size_t)(((sample - 1u) >> segShift) - ex.segBase) * n + pixNow);
               part[0] = coldF(3); part[1] = coldF(4); part[2] = coldF(5);
             } else
@@ -636,7 +638,6 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
             hr.throughput = {tp.x, tp.y, tp.z};
             hr.geom_id = (uint16_t)oGeom; hr.flags = (uint16_t)oFlags;
             res->h = hr;
-            if (ex.rngState) ex.rngState[pixNow] = rng;
             ph = PH_FETCH;
           }
         } else {

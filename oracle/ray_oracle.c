@@ -947,10 +947,22 @@ void o_path_trace_nif_pixel_rng(const oscene* sc, const onif* nif, float azimuth
   float* u = (float*)malloc(sizeof(float) * n);
   float* v = (float*)malloc(sizeof(float) * n);
   float* bgr = (float*)malloc(sizeof(float) * 3 * n);
-  for (size_t i = 0; i < n; ++i) pixel_stream_seed(states + 2 * i, sc->rngSeed, rays[i].u, rays[i].v);
+  /* Same stream definition as the plain render (o_segment_samples): a new stream at every segment boundary, the
+   * finished segments' partial sums added in segment order, segment 0 accumulating onto rgb_in directly. */
+  const uint32_t segLen = o_segment_samples(sc->samplesPerPixel);
+  ovec3* total = (ovec3*)malloc(sizeof(ovec3) * (n ? n : 1));
   ostats tot = {0, 0, 0, 0};
   if (numThreads < 1) numThreads = 1;
   for (uint32_t smp = 0; smp < sc->samplesPerPixel; ++smp) {
+    if (smp % segLen == 0) {
+      const uint32_t segment = smp / segLen;
+      for (size_t i = 0; i < n; ++i) {
+        pixel_stream_seed_segment(states + 2 * i, sc->rngSeed, rays[i].u, rays[i].v, segment);
+        if (segment == 1) total[i] = rays[i].rgb;
+        else if (segment > 1) total[i] = vadd(total[i], rays[i].rgb);
+        if (segment > 0) rays[i].rgb = V(0.f, 0.f, 0.f);
+      }
+    }
 #pragma omp parallel num_threads(numThreads)
     {
       ostats loc = {0, 0, 0, 0};
@@ -966,6 +978,8 @@ void o_path_trace_nif_pixel_rng(const oscene* sc, const onif* nif, float azimuth
     o_nif_infer(nif, u, v, n, bgr);
     o_apply_env(rays, n, bgr);
   }
+  if (sc->samplesPerPixel > segLen)
+    for (size_t i = 0; i < n; ++i) rays[i].rgb = vadd(total[i], rays[i].rgb);
   if (st) { st->casts += tot.casts; st->nodesVisited += tot.nodesVisited; st->leafTests += tot.leafTests; st->paths += tot.paths; }
-  free(states); free(u); free(v); free(bgr);
+  free(states); free(u); free(v); free(bgr); free(total);
 }

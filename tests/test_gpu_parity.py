@@ -552,17 +552,20 @@ def test_rank_streams_render_like_the_whole_frame(scenes, world):
     dev.close()
 
 
-@pytest.mark.parametrize("spl", ["32", "4", "1"])
-def test_nif_render_sample_batching_is_order_exact(scenes, spl, monkeypatch):
-    """NIF renders trace several samples per launch and replay the reference's per-sample order afterwards
-    (rgb += radiance, then rgb += throughput * env). Whatever the samples-per-launch setting (32 default, 4, 1;
-    19 spp is a multiple of none), the whole TraceResult stream must equal, bit for bit, the literal per-sample loop
-    {trace 1 sample; uv pre-pass; MLP; env add} that MI_RAYLIB_KERNEL=0 still runs with the nested-loop kernel."""
+@pytest.mark.parametrize("spl,spp", [("32", 53), ("16", 53), ("64", 53), ("1", 19), ("64", 700), ("128", 700)])
+def test_nif_render_sample_batching_is_order_exact(scenes, spl, spp, monkeypatch):
+    """NIF renders trace several samples per launch - whole segments, as (pixel, segment) work atoms - and replay the
+    reference's per-sample order afterwards (rgb += radiance, then rgb += throughput * env, per segment; segments
+    added in order). Whatever the samples-per-launch setting (rounded up to whole segments: 16 samples below 640 spp,
+    64 from there; 53 and 700 spp end in partial segments), the whole TraceResult stream must equal, bit for bit, the
+    literal per-sample loop {trace 1 sample; uv pre-pass; MLP; env add} that MI_RAYLIB_KERNEL=0 still runs with the
+    nested-loop kernel, re-seeding and rolling the partial sum at every segment boundary."""
     rng = np.random.default_rng(8)
     ks, bs, relu = _nif_weights(rng, hidden=64, embed=12, layers=4)
     mean = np.array([-2.35, -2.26, -1.96], np.float32)
     s = scenes["spheres"]; d = s.desc
-    d.set_image(80, 56); d.samples_per_pixel = 19; d.path_trace = 1
+    d.set_image(80, 56) if spp < 100 else d.set_image(24, 16)
+    d.samples_per_pixel = spp; d.path_trace = 1
 
     def render(kernel):
         monkeypatch.setenv("MI_RAYLIB_KERNEL", kernel)
@@ -579,7 +582,7 @@ def test_nif_render_sample_batching_is_order_exact(scenes, spl, monkeypatch):
     batched = render("1")
     monkeypatch.setenv("MI_RAYLIB_KERNEL", "1"); monkeypatch.setenv("MI_RAYLIB_NIF_SPL", "32")
     irl.IpuScene(d).close()                                  # restore the defaults for later tests
-    assert_streams_identical(batched, literal, f"NIF render, {spl} samples per launch")
+    assert_streams_identical(batched, literal, f"NIF render, {spp} spp, {spl} samples per launch")
     assert np.stack([batched["rgb"][k] for k in "xyz"], 1).max() > 0
 
 
