@@ -1,6 +1,6 @@
 """Differential campaign: the HIP path against the CPU oracle on seeded random cases, for a time budget.
 
-    python tests/fuzz_parity.py [seconds=240] [seed=1] [size_scale=1]
+    python tests/fuzz_parity.py [seconds=240] [seed=1] [size_scale=1] [nif]
 
 Not collected by pytest (run it on a GPU box; it is test infrastructure like the rest of tests/). Every case draws
 a scene (built-in scenes, or a random triangle soup with nasty triangles: zero-area, needle, axis-aligned and
@@ -8,6 +8,11 @@ duplicated/coplanar ones, with or without vertex normals, plus spheres and discs
 incl. ragged widths, crop window, 1..900 samples so that both segment lengths and their boundaries are crossed, seed, jitter, path length,
 roulette depth), a render mode and a kernel variant, renders it with the library and with the oracle, and compares
 every byte of every TraceResult. The first mismatch stops the run with the case's parameters (exit code 1).
+
+With a fourth argument `nif` the cases are renders with a NIF environment (random small MLP, random samples per
+launch and HDRI rotation): the batched persistent-kernel form must equal the literal per-sample loop
+(MI_RAYLIB_KERNEL=0) bit for bit - both run the same MLP kernel, so there is no tolerance - whatever the launch
+partition.
 """
 import os
 import sys
@@ -89,7 +94,67 @@ def differing(a, b):
     return np.nonzero((ab != bb).any(axis=1))[0]
 
 
+def nif_weights(rng, hidden, embed, layers):
+    F = 4 * embed
+    dims = [(F, hidden)] + [((hidden + F) if l == layers // 2 else hidden, hidden) for l in range(1, layers)] + [(hidden, 3)]
+    ks = [(rng.normal(size=d) * np.sqrt(2.0 / d[0])).astype(np.float16).astype(np.float32) for d in dims]
+    bs = [(rng.normal(size=d[1]) * 0.05).astype(np.float32) for d in dims]
+    return ks, bs, [1] * (len(dims) - 1) + [0]
+
+
+def nif_campaign(budget, seed):
+    rng = np.random.default_rng(seed)
+    builtins = {n: irl.HostScene.builtin(n) for n in ("box-simple", "box", "spheres", "monkey")}
+    t_end = time.time() + budget
+    case = rays_total = 0
+    while time.time() < t_end:
+        case += 1
+        name = str(rng.choice(list(builtins))); s = builtins[name]; d = s.desc
+        w = int(rng.integers(1, 12)) * 8 + int(rng.integers(0, 2)) * int(rng.integers(1, 8))
+        h = int(rng.integers(1, 10)) * 8 + int(rng.integers(0, 2)) * int(rng.integers(1, 8))
+        d.set_image(w, h)
+        spp = int(rng.choice([1, 2, 15, 16, 17, 33, 100, 639, 640, 641, 705])) if rng.random() < 0.5 else int(rng.integers(1, 60))
+        if w * h * spp > 4e5:
+            spp = max(1, int(4e5 // (w * h)))
+        d.samples_per_pixel = spp; d.path_trace = 1
+        d.rng_seed = int(rng.integers(0, 2**63)); d.anti_alias_scale = float(rng.choice([0.0, 0.25, 1.0]))
+        d.max_path_length = int(rng.integers(1, 12)); d.roulette_start_depth = int(rng.integers(0, 6))
+        hidden = int(rng.choice([32, 64, 128, 256, 320])); layers = int(rng.integers(2, 7))
+        ks, bs, relu = nif_weights(rng, hidden, 12, layers)
+        spl = str(rng.choice(["1", "16", "32", "48", "64", "128", ""]))
+        rot = float(rng.uniform(-180, 180))
+        desc = (f"case {case} (seed {seed}): {name} {w}x{h} spp={spp} rngseed={d.rng_seed} aa={d.anti_alias_scale} len={d.max_path_length} "
+                f"roulette={d.roulette_start_depth} mlp={layers}x{hidden} spl={spl or 'default'} rot={rot:.2f}")
+
+        def render(kernel):
+            os.environ["MI_RAYLIB_KERNEL"] = kernel
+            if spl:
+                os.environ["MI_RAYLIB_NIF_SPL"] = spl
+            else:
+                os.environ.pop("MI_RAYLIB_NIF_SPL", None)
+            dev = irl.IpuScene(d)
+            dev.setNif(ks, bs, relu, 12, 3.43, np.array([-2.35, -2.26, -1.96], np.float32), True)
+            dev.setHdriRotation(rot)
+            rays = s.init_ray_stream()
+            dev.run(rays, irl.MODE_PATH_TRACE)
+            dev.close()
+            return rays
+
+        literal, batched = render("0"), render("1")
+        bad = differing(batched, literal)
+        if bad.size:
+            i = int(bad[0])
+            print(f"MISMATCH {desc}\n {bad.size}/{batched.size} TraceResults differ; first at {i}:\n batched {batched[i]}\n literal {literal[i]}", flush=True)
+            sys.exit(1)
+        rays_total += batched.size
+        if case % 20 == 0:
+            print(f"{case} NIF cases, {rays_total} TraceResults identical; last: {desc}", flush=True)
+    print(f"OK: {case} NIF cases, {rays_total} TraceResults, batched form bit-identical to the literal per-sample loop (seed {seed}, {budget:.0f} s)")
+
+
 def main():
+    if len(sys.argv) > 4 and sys.argv[4] == "nif":
+        return nif_campaign(float(sys.argv[1]), int(sys.argv[2]))
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1            # image edges up to 160 x scale pixels
