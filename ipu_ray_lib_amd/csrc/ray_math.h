@@ -164,11 +164,18 @@ MI_HD uint32_t f2u_sat(float f) {
 // (j = 0: the plain per-pixel seed) and its own partial rgb sum, added in segment order. The work
 // atom of the persistent kernel is (pixel, segment): with pixel x all-samples atoms a 1440^2 x 1000 spp frame gives
 // every lane only 6 atoms, and the drain at the end of the frame cost a third of the throughput. The length is a
-// function of the render's sample count alone (never of the batch, crop or GPU count): 64 from 640 spp up (the measured crossover), where
-// the per-atom cost (fetch, seed, partial sum) shows and there are atoms enough; 16 below, where the drain matters
-// more (64 spp: 11.3e9 instead of 9.0e9 casts/s on the 1440^2 box frame; 1000 spp: 13.1e9 instead of 12.8e9).
-constexpr uint32_t kSegmentSamplesLong = 64, kSegmentSamplesShort = 16, kSegmentLongFromSpp = 640;
-MI_HD uint32_t segment_samples(uint32_t samplesPerPixel) { return samplesPerPixel >= kSegmentLongFromSpp ? kSegmentSamplesLong : kSegmentSamplesShort; }
+// function of the render's sample count alone (never of the batch, crop or GPU count): about sixteen segments per
+// pixel - samplesPerPixel / 16 rounded up to a power of two - but no shorter than 4 samples (every atom costs a
+// fetch, a seed and a partial sum) and no longer than 64 (atoms enough for every lane's drain to be short).
+// Measured on the 1440^2 box frame: 16 spp 8.1e9 -> 10.0e9 casts/s, 64 spp 9.0e9 -> 11.5e9 against one atom per
+// pixel; 1000 spp 13.1e9 with 64-sample segments against 12.8e9 with 16-sample ones.
+constexpr uint32_t kSegmentSamplesMin = 4, kSegmentSamplesMax = 64, kSegmentsPerPixel = 16;
+MI_HD uint32_t segment_shift(uint32_t samplesPerPixel) {
+  const uint32_t want = (samplesPerPixel + kSegmentsPerPixel - 1) / kSegmentsPerPixel;          // ceil(spp / 16)
+  const uint32_t shift = want <= 1u ? 0u : 32u - (uint32_t)__builtin_clz(want - 1u);              // ceil(log2(want))
+  return shift < 2u ? 2u : shift > 6u ? 6u : shift;                                               // 4 ... 64 samples
+}
+MI_HD uint32_t segment_samples(uint32_t samplesPerPixel) { return 1u << segment_shift(samplesPerPixel); }
 MI_HD void rng_seed_pixel_segment(Rng& r, uint64_t userSeed, float row, float col, uint32_t segment) {
   const uint64_t pix = ((uint64_t)f2u_sat(row) << 32) | (uint64_t)f2u_sat(col);
   rng_seed(r, (userSeed ^ ((pix + 1ull) * 0x9e3779b97f4a7c15ull)) ^ ((uint64_t)segment * 0xd1b54a32d192ed03ull));

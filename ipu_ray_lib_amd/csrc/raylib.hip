@@ -379,7 +379,7 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
         // MLP runs on the compacted escaped slots, and a per-pixel pass adds everything in the reference's order
         if ((uint64_t)cnt * S.scratchSamples > 0xFFFFFFFFull) throw ArgError("mi_render: ray batch too large for a NIF render (cut it with mi_scene_set_ray_batch)");
         S.nif.ensureIndex((size_t)cnt * S.scratchSamples);
-        const uint32_t segLen = segment_samples(S.ds.samplesPerPixel), segShift = segLen == kSegmentSamplesLong ? 6u : 4u;
+        const uint32_t segLen = segment_samples(S.ds.samplesPerPixel), segShift = segment_shift(S.ds.samplesPerPixel);
         for (uint32_t s0 = 0; s0 < S.ds.samplesPerPixel; s0 += S.scratchSamples) {
           const uint32_t sc = std::min<uint32_t>(S.scratchSamples, S.ds.samplesPerPixel - s0);
           HIP_CHECK(hipMemsetAsync(S.nif.d_count, 0, sizeof(uint32_t), stream));

@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
   const uint32_t numNodes = sc.numNodes;
   const uint32_t spp = ex.sampleCount ? ex.sampleCount : sc.samplesPerPixel;
   const bool segd = !TWO_RAYS && (ex.segPart != nullptr || ex.slotColor != nullptr);          // (pixel, segment) work atoms
-  const uint32_t segShift = segment_samples(sc.samplesPerPixel) == kSegmentSamplesLong ? 6u : 4u, segMask = (1u << segShift) - 1u;
+  const uint32_t segShift = segment_shift(sc.samplesPerPixel), segMask = (1u << segShift) - 1u;
   const uint32_t segs = segd ? ex.segments : 1u;
   const uint32_t items = n * segs;                 // (host checks that this fits 32 bits)
 

@@ -737,12 +737,17 @@ static uint32_t f2u_sat(float f) {
 /* Per-pixel stream seed: one xoroshiro128** state per image pixel, derived
  * from the user seed and the pixel's (row, col) in FULL-image coordinates, so the image does
  * not depend on crop windows, batch sizes or the number of GPUs. */
-/* Tier-1 stream definition: a pixel's samples are cut into SEGMENTS of o_segment_samples(spp) - 64
- * samples from 640 spp up, 16 below, a function of the render's sample count alone; segment j has its own stream,
+/* Tier-1 stream definition: a pixel's samples are cut into SEGMENTS of o_segment_samples(spp) -
+ * ceil(spp / 16) rounded up to a power of two within 4 ... 64, a function of the render's sample count alone; segment j has its own stream,
  * seeded from (seed, row, col, j) - j = 0 is the plain per-pixel seed - and its own partial rgb sum; the pixel's rgb
  * is ((rgb_in + segment 0) + segment 1) + ... in segment order, segment 0 accumulating onto rgb_in directly. Up to
  * one segment's worth of samples this is one stream and one running sum. */
-static uint32_t o_segment_samples(uint32_t samplesPerPixel) { return samplesPerPixel >= 640u ? 64u : 16u; }
+static uint32_t o_segment_samples(uint32_t samplesPerPixel) {
+  const uint32_t want = (samplesPerPixel + 15u) / 16u;      /* about sixteen segments per pixel ...           */
+  uint32_t len = 4u;                                        /* ... of a power-of-two length from 4 ...        */
+  while (len < want && len < 64u) len *= 2u;                /* ... to 64 samples                              */
+  return len;
+}
 static void pixel_stream_seed_segment(uint64_t s[2], uint64_t rngSeed, float pu, float pv, uint32_t segment) {
   const uint64_t pix = ((uint64_t)f2u_sat(pu) << 32) | (uint64_t)f2u_sat(pv);
   o_xoshiro_seed(s, (rngSeed ^ ((pix + 1ull) * 0x9e3779b97f4a7c15ull)) ^ ((uint64_t)segment * 0xd1b54a32d192ed03ull));

@@ -113,7 +113,7 @@ def nif_campaign(budget, seed):
         w = int(rng.integers(1, 12)) * 8 + int(rng.integers(0, 2)) * int(rng.integers(1, 8))
         h = int(rng.integers(1, 10)) * 8 + int(rng.integers(0, 2)) * int(rng.integers(1, 8))
         d.set_image(w, h)
-        spp = int(rng.choice([1, 2, 15, 16, 17, 33, 100, 639, 640, 641, 705])) if rng.random() < 0.5 else int(rng.integers(1, 60))
+        spp = int(rng.choice([1, 2, 4, 5, 63, 64, 65, 100, 128, 129, 257, 513, 705])) if rng.random() < 0.5 else int(rng.integers(1, 60))
         if w * h * spp > 4e5:
             spp = max(1, int(4e5 // (w * h)))
         d.samples_per_pixel = spp; d.path_trace = 1
@@ -178,7 +178,7 @@ def main():
             cw, ch = int(rng.integers(1, w + 1)), int(rng.integers(1, h + 1))
             crop = (cw, ch, int(rng.integers(0, w - cw + 1)), int(rng.integers(0, h - ch + 1)))
         d.set_image(w, h, crop)
-        spp = int(rng.choice([1, 2, 3, 5, 15, 16, 17, 31, 33, 64, 65, 150, 511, 639, 640, 641, 705, 900])) if rng.random() < 0.5 else int(rng.integers(1, 40))
+        spp = int(rng.choice([1, 2, 3, 4, 5, 17, 63, 64, 65, 128, 129, 150, 256, 257, 511, 512, 513, 705, 900])) if rng.random() < 0.5 else int(rng.integers(1, 40))
         if w * h * spp > 1.2e6 * scale:
             spp = max(1, int(1.2e6 * scale // (w * h)))
         d.samples_per_pixel = spp

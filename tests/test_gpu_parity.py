@@ -556,8 +556,8 @@ def test_rank_streams_render_like_the_whole_frame(scenes, world):
 def test_nif_render_sample_batching_is_order_exact(scenes, spl, spp, monkeypatch):
     """NIF renders trace several samples per launch - whole segments, as (pixel, segment) work atoms - and replay the
     reference's per-sample order afterwards (rgb += radiance, then rgb += throughput * env, per segment; segments
-    added in order). Whatever the samples-per-launch setting (rounded up to whole segments: 16 samples below 640 spp,
-    64 from there; 53 and 700 spp end in partial segments), the whole TraceResult stream must equal, bit for bit, the
+    added in order). Whatever the samples-per-launch setting (rounded up to whole segments: 4 samples at 19 and 53 spp,
+    64 at 700 spp; all three end in partial segments), the whole TraceResult stream must equal, bit for bit, the
     literal per-sample loop {trace 1 sample; uv pre-pass; MLP; env add} that MI_RAYLIB_KERNEL=0 still runs with the
     nested-loop kernel, re-seeding and rolling the partial sum at every segment boundary."""
     rng = np.random.default_rng(8)
@@ -619,9 +619,9 @@ def test_randomised_render_parameters_against_oracle(scenes):
 
 @pytest.mark.parametrize("kernel,spp", [("0", 300), ("1", 300), ("2", 300), ("3", 300), ("4", 300), ("0", 700), ("1", 700), ("3", 700)])
 def test_segmented_pixels_bit_exact(scenes, kernel, spp, monkeypatch):
-    """More samples per pixel than one segment holds: the pixel is traced as segments (16 samples below 640 spp, 64
-    from 640 spp up), each with its own RNG stream and partial rgb sum, added in segment order.
-    300 spp = eighteen full short segments + one of 12; 700 spp = ten full long segments + one of 60; the incoming
+    """More samples per pixel than one segment holds: the pixel is traced as segments (about sixteen per pixel, 4 to 64
+    samples long), each with its own RNG stream and partial rgb sum, added in segment order.
+    300 spp = nine full 32-sample segments + one of 12; 700 spp = ten full 64-sample segments + one of 60; the incoming
     rgb is non-zero (segment 0 accumulates onto it). Every kernel variant - the persistent kernel traces (pixel,
     segment) work atoms, the nested-loop kernel loops over the segments in one thread, the two-rays variant falls
     back to it - must reproduce the oracle bit for bit; so must a batched render (both pipeline slots, each with its own partial-sum buffer)."""
