@@ -742,7 +742,7 @@ static uint32_t f2u_sat(float f) {
  * seeded from (seed, row, col, j) - j = 0 is the plain per-pixel seed - and its own partial rgb sum; the pixel's rgb
  * is ((rgb_in + segment 0) + segment 1) + ... in segment order, segment 0 accumulating onto rgb_in directly. Up to
  * one segment's worth of samples this is one stream and one running sum. */
-static uint32_t o_segment_samples(uint32_t samplesPerPixel) {
+uint32_t o_segment_samples(uint32_t samplesPerPixel) {
   const uint32_t want = (samplesPerPixel + 15u) / 16u;      /* about sixteen segments per pixel ...           */
   uint32_t len = 4u;                                        /* ... of a power-of-two length from 4 ...        */
   while (len < want && len < 64u) len *= 2u;                /* ... to 64 samples                              */

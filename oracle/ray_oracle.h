@@ -155,6 +155,9 @@ typedef struct {
 void o_nif_infer(const onif* nif, const float* u, const float* v, size_t n, float* bgr);
 void o_apply_env(otrace* rays, size_t n, const float* bgr);   /* PostProcessEscapedRays */
 
+/* Tier-1 stream definition: samples per segment for a render of samplesPerPixel */
+uint32_t o_segment_samples(uint32_t samplesPerPixel);
+
 /* Per-sample NIF path trace (src/IpuScene.cpp:571-583: Repeat(spp){trace; pre; nif; post}) with per-pixel RNG */
 void o_path_trace_nif_pixel_rng(const oscene* sc, const onif* nif, float azimuthRotation,
                                 otrace* rays, size_t n, int numThreads, ostats* st);

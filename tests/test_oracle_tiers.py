@@ -49,3 +49,24 @@ def test_shared_rng_and_pixel_rng_agree_statistically():
     b1 = s.init_ray_stream(); ol.path_trace_shared_rng(d, b1)
     b2 = s.init_ray_stream(); ol.path_trace_shared_rng(d, b2)
     assert b1.tobytes() == b2.tobytes()
+
+
+def test_segment_length_rule_is_the_same_in_the_product_header_and_the_oracle(tmp_path):
+    """The tier-1 stream definition cuts a pixel's samples into segments whose length depends on the sample count
+    (DESIGN.md §4): ceil(spp / 16) rounded up to a power of two, within 4 ... 64. The product header (ray_math.h,
+    compiled here for the host), the oracle and this restatement must agree for every sample count."""
+    import ctypes as C
+    import subprocess
+    src = tmp_path / "seg.cpp"
+    src.write_text('#include <cstdio>\n#include "ray_math.h"\nint main() { for (unsigned s = 0; s <= 5000; ++s) std::printf("%u %u\\n", mi::segment_samples(s), mi::segment_shift(s)); }\n')
+    exe = tmp_path / "seg"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", str(ol.ROOT / "ipu_ray_lib_amd" / "csrc"), "-I", str(ol.ROOT / "include"), "-o", str(exe), str(src)], check=True)
+    rows = [tuple(map(int, line.split())) for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines()]
+    lib = ol.lib()
+    lib.o_segment_samples.restype = C.c_uint32; lib.o_segment_samples.argtypes = [C.c_uint32]
+    for spp, (length, shift) in enumerate(rows):
+        want = 4
+        while want < -(-spp // 16) and want < 64:
+            want *= 2
+        assert length == want == lib.o_segment_samples(spp) and length == 1 << shift, (spp, length, shift, want)
+    assert [rows[s][0] for s in (1, 64, 65, 128, 129, 256, 257, 512, 513, 1000, 4000)] == [4, 4, 8, 8, 16, 16, 32, 32, 64, 64, 64]
