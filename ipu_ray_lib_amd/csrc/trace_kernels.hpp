@@ -76,6 +76,18 @@ __device__ __forceinline__ Shear make_shear(f3 d) {
   s.sz = 1.f / dz;
   return s;
 }
+// The same with the ray's reciprocal direction at hand: 1 / d[kz] is one of its components (the same IEEE division).
+__device__ __forceinline__ Shear make_shear(f3 d, f3 inv) {
+  Shear s;
+  s.kz = min_index(d);
+  uint32_t kx = s.kz + 1; if (kx == 3) kx = 0;
+  uint32_t ky = kx + 1; if (ky == 3) ky = 0;
+  const float dx = comp(d, kx), dy = comp(d, ky), dz = comp(d, s.kz);
+  s.sx = -dx / dz;
+  s.sy = -dy / dz;
+  s.sz = comp(inv, s.kz);
+  return s;
+}
 
 __device__ __forceinline__ f3 permute_kz(f3 p, uint32_t kz) {
   // (kx,ky,kz) is the cyclic rotation that puts component kz last. Written as selects: as three early returns

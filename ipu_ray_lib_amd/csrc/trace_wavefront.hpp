@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
           o = offset_origin(o, d, nrm);
           inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
           exactSlab = !(fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf && fabsf(o.x) < kInf && fabsf(o.y) < kInf && fabsf(o.z) < kInf);
-          sh = make_shear(d);
+          sh = make_shear(d, inv);
           hit.t = kInf; hit.leaf = 0xFFFFFFFFu;
           node = 0;
           ++casts;
@@ -699,7 +699,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
         o = offset_origin(o, d, nrm);
         inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
         exactSlab = !(fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf && fabsf(o.x) < kInf && fabsf(o.y) < kInf && fabsf(o.z) < kInf);
-        sh = make_shear(d);
+        sh = make_shear(d, inv);
         hit.t = kInf; hit.leaf = 0xFFFFFFFFu;
         node = 0;
         ++casts;
