@@ -193,6 +193,7 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
         L.f[0] = c.nx; L.f[1] = c.ny; L.f[2] = c.nz; L.f[3] = c.cx; L.f[4] = c.cy; L.f[5] = c.cz; L.f[6] = c.r * c.r;
         L.type = LEAF_DISC | ((uint32_t)n.geom_id << 16); L.primID = 0;
       }
+      L.matIndex = d.mat_ids[n.geom_id];
       g.link = (uint32_t)leaves.size();
       leaves.push_back(L);
     }

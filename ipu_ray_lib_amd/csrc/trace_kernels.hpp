@@ -42,7 +42,7 @@ struct __attribute__((aligned(16))) GLeaf {       // 64 B pre-resolved primitive
   float n[3];        // tri: the face normal normalise(cross(p1-p0, p2-p0)) (Mesh.hpp:112-114), evaluated once at
                      // upload with the same binary32 operations the reference performs per hit (no contraction,
                      // correctly rounded sqrt and divide on both sides), so SHADE just reads it
-  uint32_t pad;
+  uint32_t matIndex; // matIDs[geomID], resolved at upload (one dependent load less when a hit is shaded)
 };
 static_assert(sizeof(GLeaf) == 64, "GLeaf must stay 64 bytes");
 __host__ __device__ __forceinline__ uint32_t leaf_kind(const GLeaf& L) { return L.type & 0xFFFFu; }

@@ -565,7 +565,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
           if (TWO_RAYS) { oLeaf = hit.leaf; oTmax = hit.t; } else { coldU(6) = hit.leaf; coldF(7) = hit.t; }
           o = o + d * hit.t;                                          // updateHit, Render.hpp:15-23
           nrm = hit_normal(sc, hit, o);
-          const mi_material mat = sc.materials[sc.matIDs[hit.geomID]];
+          const mi_material mat = sc.materials[L.matIndex];           // = materials[matIDs[geomID]]
           const f3 albedo = mk(mat.albedo.x, mat.albedo.y, mat.albedo.z);
           if (mat.emissive) color = color + tp * mk(mat.emission.x, mat.emission.y, mat.emission.z);
           if (mat.type == 0) {
