@@ -10,7 +10,7 @@
 //     FETCH work unit finished: write it back, take another one from the global work counter
 // and each loop iteration the wave votes (ballot + popcount, scalar) and runs the phase most of its
 // lanes are waiting in. A lane that finishes a path immediately starts its next sample, a lane that
-// finishes a work unit - a pixel, or a 16- or 64-sample segment of one (ray_math.h) - pulls a new one, so no lane
+// finishes a work unit - a 4- to 64-sample segment of a pixel (ray_math.h) - pulls a new one, so no lane
 // idles until the frame runs out of work; units are small on purpose, the drain at the end of a frame is paid
 // per unit. The kernel is bound by the latency of each wave's dependent chain (node load -> box test -> vote),
 // so the scheduling below is about few, short chains: several box tests per vote, whole 8x8 tiles per wave,
