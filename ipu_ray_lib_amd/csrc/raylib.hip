@@ -268,7 +268,7 @@ void ensureScratch(mi_scene& S, size_t n) {
 }
 
 bool g_fullStats = false;
-WaveTune g_tune = {5, 16, 24, 48, 3, 16};
+WaveTune g_tune = {5, 16, 24, 48, 3};
 int g_kernelChoice = 1;           // 0 = nested-loop kernel, 1 = wavefront (global nodes), 2 = wavefront + LDS-staged nodes
 int g_wavesPerSimd = 5;          // MI_RAYLIB_WAVES=4: the 108-VGPR build of the default kernel (4 waves per SIMD)
 
@@ -284,9 +284,7 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
   const uint32_t tileW = (!noTiles && w >= 8 && (w % 8) == 0 && cnt >= 8u * w) ? w : 0u;
   const bool plain = ex.slotColor == nullptr;      // NIF launches (slots) only exist for the default kernel
   // Pixels with more than segment_samples(spp) samples are traced as (pixel, segment) work atoms (ray_math.h); the two
-  // pipeline slots of mi_render run on different streams, so each has its own partial-sum buffer. The
-  // two-rays-per-lane variant, which keeps rgb in memory, falls back to the nested-loop kernel's in-thread
-  // segment loop - the results are the same by definition.
+  // pipeline slots of mi_render run on different streams, so each has its own partial-sum buffer.
   const uint32_t segLen = segment_samples(S.ds.samplesPerPixel);
   const uint32_t segments = (S.ds.samplesPerPixel + segLen - 1) / segLen;
   const bool segmented = plain && segments > 1;
@@ -320,31 +318,18 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
       // one 1024-thread workgroup per CU shares one LDS copy of the first nodes of the (preorder) array
       const uint32_t ldsNodes = std::min<uint32_t>(S.ds.numNodes, kLdsBudgetBytes / (uint32_t)sizeof(GNode));
       const size_t ldsBytes = (size_t)ldsNodes * sizeof(GNode);
-      auto kern = path_trace_wavefront_kernel<STATS, true, 1024, false>;
+      auto kern = path_trace_wavefront_kernel<STATS, true, 1024>;
       static bool attrSet = false;
       if (!attrSet) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes)); attrSet = true; }
       const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 1023) / 1024, 256);
       hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, ldsNodes, g_tune, tileW, exs);
-    } else if (plain && g_kernelChoice == 3 && !S.ds.hasNormals) {
-      // two rays per lane, the second parked in LDS: 9 uint4 groups x 64 lanes x 4 waves = 36 KiB per workgroup
-      const size_t ldsBytes = (size_t)kParkBytesPerWave * (256 / 64);
-      const uint32_t blocks = std::min<uint32_t>((cnt + 511) / 512, 256 * 4);
-      hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, true>), dim3(blocks), dim3(256), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, exs);
-    } else if (g_kernelChoice == 4) {
-      // primitive tests pooled across the workgroup (LEAFQ): 17 KiB of LDS per workgroup
-      const bool five = !STATS && g_wavesPerSimd == 5;
-      const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 255) / 256, 256 * 8);
-      if (five)
-        hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, false, 5, true>), dim3(blocks), dim3(256), kLeafQBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, exs);
-      else
-        hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, false, 4, true>), dim3(blocks), dim3(256), kLeafQBytes, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, exs);
     } else if (!STATS && g_wavesPerSimd == 5) {
-      // 96-VGPR build: 5 waves per SIMD (+4.6 % on the box scene; 6 waves = 80 VGPRs: -15 %, its spills land in LEAF/SHADE)
+      // 96-VGPR build: 5 waves per SIMD (+4.6 % on the box scene; 6 waves = 80 VGPRs: -19 %, its spills land in LEAF/SHADE)
       const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 255) / 256, 256 * 8);
-      hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, false, 5>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, exs);
+      hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, 5>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, exs);
     } else {
       const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 255) / 256, 256 * 8);
-      hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, false>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, exs);
+      hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, exs);
     }
     if (segmented) hipLaunchKernelGGL(segment_combine_kernel, dim3((cnt + 255) / 256), dim3(256), 0, stream, d_rays, cnt, exs.segments, S.d_segPart[slot], segBase ? 1u : 0u);
   }
@@ -360,9 +345,7 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
     if (g_fullStats) hipLaunchKernelGGL(shadow_trace_kernel<true>, grid, block, 0, stream, S.ds, d_rays, cnt, .05f, light);
     else hipLaunchKernelGGL(shadow_trace_kernel<false>, grid, block, 0, stream, S.ds, d_rays, cnt, .05f, light);
   } else if (mode == MI_MODE_PATH_TRACE) {
-    const bool segmentedFrame = S.ds.samplesPerPixel > segment_samples(S.ds.samplesPerPixel);
-    const bool waveOk = !(segmentedFrame && g_kernelChoice == 3);     // see launchWavefront
-    if (!S.nif.loaded() && g_kernelChoice != 0 && waveOk && S.ds.samplesPerPixel >= 1 && S.ds.maxPathLength >= 1) {
+    if (!S.nif.loaded() && g_kernelChoice != 0 && S.ds.samplesPerPixel >= 1 && S.ds.maxPathLength >= 1) {
       // sample loop inside the kernel (src/IpuScene.cpp:441), phase-scheduled persistent form
       if (g_fullStats) launchWavefront<true>(S, d_rays, cnt, stream, slot);
       else launchWavefront<false>(S, d_rays, cnt, stream, slot);
@@ -438,9 +421,12 @@ int mi_scene_create(const mi_scene_desc* desc, mi_scene** out) {
     S->params.mesh_normals = nullptr; S->params.mat_ids = nullptr; S->params.materials = nullptr; S->params.bvh_nodes = nullptr;
     S->params.spheres = nullptr; S->params.discs = nullptr;
     if (const char* e = getenv("MI_RAYLIB_FULL_STATS")) g_fullStats = (e[0] == '1');
-    if (const char* e = getenv("MI_RAYLIB_TUNE")) { unsigned a, b, c, dd = 48, k8 = 3, ta = 16, qp = 4, qs = 48, db = 6, mx = 5, ln = 1, pr = 1; if (sscanf(e, "%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u", &a, &b, &c, &dd, &k8, &ta, &qp, &qs, &db, &mx, &ln, &pr) >= 3) g_tune = {a, b, c, dd, k8, ta, qp, qs, db ? db : 65, mx, ln, pr}; }
+    if (const char* e = getenv("MI_RAYLIB_TUNE")) {      // leafAt,shadeAt,genAt[,burst,keep8,dbl,maxExtra,leafThenNode,prio]
+      unsigned a, b, c, dd = 48, k8 = 3, db = 6, mx = 5, ln = 1, pr = 1;
+      if (sscanf(e, "%u,%u,%u,%u,%u,%u,%u,%u,%u", &a, &b, &c, &dd, &k8, &db, &mx, &ln, &pr) >= 3) g_tune = {a, b, c, dd, k8, db ? db : 65, mx, ln, pr};
+    }
     if (const char* e = getenv("MI_RAYLIB_WAVES")) g_wavesPerSimd = (e[0] == '4') ? 4 : 5;
-    if (const char* e = getenv("MI_RAYLIB_KERNEL")) g_kernelChoice = (e[0] == '0') ? 0 : (e[0] == '2') ? 2 : (e[0] == '3') ? 3 : (e[0] == '4') ? 4 : 1;
+    if (const char* e = getenv("MI_RAYLIB_KERNEL")) g_kernelChoice = (e[0] == '0') ? 0 : (e[0] == '2') ? 2 : 1;
   });
   if (rc != MI_OK) { delete S; return rc; }
   *out = S;

@@ -24,33 +24,7 @@
 
 namespace mi {
 
-// TWO_RAYS variant: a wave owns 128 pixels' state machines — 64 in registers (one per lane,
-// "active") and 64 parked in LDS (36 dwords each, 9 KiB per wave). The vote counts both sets; before a
-// phase runs, lanes whose active ray is NOT waiting for that phase trade it for ANY parked ray that is
-// (ranks from two ballots, matched through a 64-entry LDS list, then 9 b128 LDS reads + writes). A phase
-// therefore executes with min(64, rays waiting for it among 128) lanes. The rays themselves are processed
-// exactly as before, so results are unchanged.
-constexpr uint32_t kParkGroups = 9;      // uint4 groups per parked ray
-constexpr uint32_t kParkBytesPerWave = kParkGroups * 64 * 16 + 2 * 64 * 4;   // + phase words + match list
-
-enum : uint32_t { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_GEN = 3, PH_FETCH = 4, PH_DONE = 5, PH_WAIT = 6 };
-
-// LEAFQ variant: primitive tests are pooled across the WORKGROUP. A lane that reaches a leaf
-// writes a request (origin, direction, shear, leaf index: 11 dwords) into its own LDS slot, appends its thread
-// id to a 256-entry ring and waits (PH_WAIT). Whichever wave next finds 64 requests in the ring claims them
-// (compare-and-swap on the ring head) and runs ONE primitive test per lane for them - 64 of 64 lanes busy instead
-// of the ~15 a single wave has waiting - then posts each result to its owner's mailbox; the owner picks it up at
-// its next poll and continues its walk. Every ray still sees its own leaf tests in its own order with the same
-// arithmetic, so results are unchanged. LDS protocol (all accesses volatile; one wave's LDS operations execute
-// in order, and the LDS serialises operations of different waves):
-//   producer: request words -> atomicAdd(reserved, n) -> ring[pos] = tid
-//   consumer: CAS(head, h, h + k) with k <= reserved - h -> spin until ring[pos] != EMPTY -> ring[pos] = EMPTY
-//             -> result words -> flag[owner] = 1
-//   owner:    flag[tid] == 1 -> read result -> flag[tid] = 0
-// A thread has at most one request outstanding, so 256 ring entries can never overflow.
-constexpr uint32_t kLeafQReqWords = 11;
-constexpr uint32_t kLeafQBytes = (kLeafQReqWords + 4 + 1 + 1) * 256 * 4 + 16;   // requests, results, flags, ring, {head, reserved}
-constexpr uint32_t kLeafQEmpty = 0xFFFFFFFFu;
+enum : uint32_t { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_GEN = 3, PH_FETCH = 4, PH_DONE = 5 };
 
 // Scheduling weights (quarter units, NODE/TRAVERSE weigh 4) and traversal-burst limits; the defaults
 // {5, 16, 24, 48, 3} are the measured optimum on the box scene (+-2 % plateau):
@@ -62,7 +36,7 @@ constexpr uint32_t kLeafQEmpty = 0xFFFFFFFFu;
 //   leafThenNode    a box test follows every LEAF turn at once
 //   prio     1: waves run their traversal turns at s_setprio 1 (short dependent steps win VALU arbitration over
 //            another wave's long SHADE/GEN blocks: +1 %), 0: no priorities
-struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, tradeAt, qPush = 4, qServe = 48, dbl = 6, maxExtra = 5, leafThenNode = 1, prio = 1; };
+struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, dbl = 6, maxExtra = 5, leafThenNode = 1, prio = 1; };
 
 // Per-launch extras for renders with the NIF environment. The reference traces ONE sample, evaluates the
 // environment for the rays that escaped, adds it, and repeats (src/IpuScene.cpp:571-583). One sample per launch
@@ -93,8 +67,8 @@ struct WaveExtras {
   uint32_t segBase = 0;
 };
 
-template <bool STATS, bool LDS_NODES, int BLOCK, bool TWO_RAYS, int WAVES_PER_SIMD = 4, bool LEAFQ = false>
-__global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK == 256 && (WAVES_PER_SIMD > 4 || LEAFQ)) ? WAVES_PER_SIMD : 1) path_trace_wavefront_kernel(DeviceScene sc, mi_trace_result* rays, uint32_t n,
+template <bool STATS, bool LDS_NODES, int BLOCK, int WAVES_PER_SIMD = 4>
+__global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? WAVES_PER_SIMD : 1) path_trace_wavefront_kernel(DeviceScene sc, mi_trace_result* rays, uint32_t n,
                                                                    uint32_t* workCounter, uint32_t ldsNodeCount, WaveTune tune, uint32_t tileStreamW, WaveExtras ex) {
   __shared__ float sinTbl[92];
   extern __shared__ __attribute__((aligned(16))) unsigned char dynLds[];
@@ -108,25 +82,13 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
     __syncthreads();
   }
 
-  // LEAFQ: workgroup-shared request slots, mailboxes and ring (see the protocol above)
-  volatile uint32_t* qReq = reinterpret_cast<volatile uint32_t*>(dynLds);          // [word][tid]
-  volatile uint32_t* qRes = qReq + kLeafQReqWords * 256;                             // [4][tid]: t, b0, b1, b2
-  volatile uint32_t* qFlag = qRes + 4 * 256;
-  volatile uint32_t* qRing = qFlag + 256;
-  uint32_t* qCtr = const_cast<uint32_t*>(qRing + 256);                               // [0] head, [1] reserved
-  if (LEAFQ) {
-    qFlag[threadIdx.x] = 0u; qRing[threadIdx.x] = kLeafQEmpty;
-    if (threadIdx.x < 2) qCtr[threadIdx.x] = 0u;
-    __syncthreads();
-  }
-
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t fetchChunk = ex.fetchChunk ? ex.fetchChunk : 64u;
   uint32_t chunkNext = 0, chunkEnd = 0;          // wave-uniform: the local range of work indices not handed out yet
   const uint32_t tiledCount = tileStreamW ? (n / (8u * tileStreamW)) * (8u * tileStreamW) : 0u;
   const uint32_t numNodes = sc.numNodes;
   const uint32_t spp = ex.sampleCount ? ex.sampleCount : sc.samplesPerPixel;
-  const bool segd = !TWO_RAYS && (ex.segPart != nullptr || ex.slotColor != nullptr);          // (pixel, segment) work atoms
+  const bool segd = ex.segPart != nullptr || ex.slotColor != nullptr;          // (pixel, segment) work atoms
   const uint32_t segShift = segment_shift(sc.samplesPerPixel), segMask = (1u << segShift) - 1u;
   const uint32_t segs = segd ? ex.segments : 1u;
   const uint32_t items = n * segs;                 // (host checks that this fits 32 bits)
@@ -140,29 +102,24 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
   f3 o = mk(0, 0, 0), d = mk(0, 0, -1), nrm = mk(0, 0, 1), inv = mk(0, 0, 0);
   Shear sh; sh.kz = 2; sh.sx = sh.sy = 0.f; sh.sz = 1.f;
   Hit hit; hit.t = kInf; hit.leaf = 0xFFFFFFFFu; hit.geomID = 0xFFFFu; hit.b0 = hit.b1 = hit.b2 = 0.f;
-  uint32_t oFlags = 0, oLeaf = 0xFFFFFFFFu;   // oLeaf: leaf record of the last hit (-> primID, geomID at pixel end)
-  uint32_t phB = (uint32_t)PH_DONE;   // TWO_RAYS: phase of the ray parked in this lane's LDS slot (re-read at every vote)
+  uint32_t oFlags = 0;
   bool exactSlab = false;
-  float oTmax = kInf;
-  // Cold per-lane state lives in LDS (6 dwords per lane, [word][thread] so a wave's accesses are conflict-free): the
-  // pixel's stream index, its (row, col) and its running rgb sum are touched once per path or per pixel, and holding
-  // them in VGPRs made the 96-register build spill inside the traversal loop. (TWO_RAYS keeps them in its parked
-  // record / in memory instead.)
-  __shared__ uint32_t coldLds[TWO_RAYS ? 1 : 23 * BLOCK];   // + the last hit's leaf and distance (6, 7) + the path state (8..22)
+  // Cold per-lane state lives in LDS (23 dwords per lane, [word][thread] so a wave's accesses are conflict-free): the
+  // pixel's stream index (0), its (row, col) (1, 2) and its running rgb sum (3..5) are touched once per path or per
+  // pixel, and holding them in VGPRs made the 96-register build spill inside the traversal loop.
+  __shared__ uint32_t coldLds[23 * BLOCK];   // + the last hit's leaf and distance (6, 7) + the path state (8..22)
   auto coldU = [&](uint32_t w) -> uint32_t& { return coldLds[w * BLOCK + threadIdx.x]; };
   auto coldF = [&](uint32_t w) -> float& { return reinterpret_cast<float*>(coldLds)[w * BLOCK + threadIdx.x]; };
-  auto getPix = [&]() -> uint32_t { return TWO_RAYS ? pix : coldU(0); };
+  auto getPix = [&]() -> uint32_t { return coldU(0); };
   // Path state that only SHADE / GEN / FETCH touch - the RNG, radiance, throughput, normal, bounce and sample
   // counters - is loaded at the top of those phases and stored at their end, so it holds no registers while the
   // wave traverses (words 8..22).
   auto pathLoad = [&]() {
-    if (TWO_RAYS) return;
     rng.s0 = (uint64_t)coldU(8) | ((uint64_t)coldU(9) << 32); rng.s1 = (uint64_t)coldU(10) | ((uint64_t)coldU(11) << 32);
     color = mk(coldF(12), coldF(13), coldF(14)); tp = mk(coldF(15), coldF(16), coldF(17)); nrm = mk(coldF(18), coldF(19), coldF(20));
     bounce = coldU(21); sample = coldU(22);
   };
   auto pathStore = [&]() {
-    if (TWO_RAYS) return;
     coldU(8) = (uint32_t)rng.s0; coldU(9) = (uint32_t)(rng.s0 >> 32); coldU(10) = (uint32_t)rng.s1; coldU(11) = (uint32_t)(rng.s1 >> 32);
     coldF(12) = color.x; coldF(13) = color.y; coldF(14) = color.z; coldF(15) = tp.x; coldF(16) = tp.y; coldF(17) = tp.z;
     coldF(18) = nrm.x; coldF(19) = nrm.y; coldF(20) = nrm.z;
@@ -173,146 +130,6 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
   // STATS only: per-wave phase executions and the lanes that were active in them (wave-uniform values)
   uint32_t itN = 0, itL = 0, itS = 0, itG = 0, lnN = 0, lnL = 0, lnS = 0, lnG = 0;
   unsigned long long tTrav = 0, tShade = 0, tGen = 0, tLoop0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;   // STATS: shader cycles per phase
-
-  // Swap the register-resident ray with the parked one. Layout: group g of lane l of wave w at
-  // park[(w*kParkGroups + g)*64 + l] (uint4): consecutive lanes 16 B apart, conflict-free b128 accesses.
-  unsigned char* waveLds = dynLds + (size_t)(threadIdx.x >> 6) * kParkBytesPerWave;
-  uint4* parkBase = reinterpret_cast<uint4*>(waveLds);
-  volatile uint32_t* pph = reinterpret_cast<volatile uint32_t*>(waveLds + kParkGroups * 64 * 16);   // phase of parked slot j
-  volatile uint32_t* cq = pph + 64;                                                                  // rank -> slot match list
-  auto swapRays = [&](uint32_t slot) {
-    uint4* park = parkBase + slot;
-    auto fu = [](float f) { return __float_as_uint(f); };
-    auto uf = [](uint32_t u) { return __uint_as_float(u); };
-    const uint32_t packed = ph | (bounce << 3) | (oFlags << 11) | (sh.kz << 13) | ((exactSlab ? 1u : 0u) << 15);
-    const uint4 w0 = make_uint4(fu(o.x), fu(o.y), fu(o.z), fu(d.x));
-    const uint4 w1 = make_uint4(fu(d.y), fu(d.z), fu(inv.x), fu(inv.y));
-    const uint4 w2 = make_uint4(fu(inv.z), fu(sh.sx), fu(sh.sy), fu(sh.sz));
-    const uint4 w3 = make_uint4(fu(hit.t), hit.leaf, node, pendLeaf);
-    const uint4 w4 = make_uint4(fu(tp.x), fu(tp.y), fu(tp.z), fu(color.x));
-    const uint4 w5 = make_uint4(fu(color.y), fu(color.z), fu(nrm.x), fu(nrm.y));
-    const uint4 w6 = make_uint4(fu(nrm.z), (uint32_t)rng.s0, (uint32_t)(rng.s0 >> 32), (uint32_t)rng.s1);
-    const uint4 w7 = make_uint4((uint32_t)(rng.s1 >> 32), pix, sample, fu(oTmax));
-    const uint4 w8 = make_uint4(oLeaf, packed, 0u, 0u);
-    const uint4 r0 = park[0 * 64], r1 = park[1 * 64], r2 = park[2 * 64], r3 = park[3 * 64], r4 = park[4 * 64];
-    const uint4 r5 = park[5 * 64], r6 = park[6 * 64], r7 = park[7 * 64], r8 = park[8 * 64];
-    park[0 * 64] = w0; park[1 * 64] = w1; park[2 * 64] = w2; park[3 * 64] = w3; park[4 * 64] = w4;
-    park[5 * 64] = w5; park[6 * 64] = w6; park[7 * 64] = w7; park[8 * 64] = w8;
-    o = mk(uf(r0.x), uf(r0.y), uf(r0.z)); d = mk(uf(r0.w), uf(r1.x), uf(r1.y));
-    inv = mk(uf(r1.z), uf(r1.w), uf(r2.x)); sh.sx = uf(r2.y); sh.sy = uf(r2.z); sh.sz = uf(r2.w);
-    hit.t = uf(r3.x); hit.leaf = r3.y; node = r3.z; pendLeaf = r3.w;
-    tp = mk(uf(r4.x), uf(r4.y), uf(r4.z)); color = mk(uf(r4.w), uf(r5.x), uf(r5.y));
-    nrm = mk(uf(r5.z), uf(r5.w), uf(r6.x));
-    rng.s0 = (uint64_t)r6.y | ((uint64_t)r6.z << 32); rng.s1 = (uint64_t)r6.w | ((uint64_t)r7.x << 32);
-    pix = r7.y; sample = r7.z; oTmax = uf(r7.w);
-    oLeaf = r8.x;
-    const uint32_t pk = r8.y;
-    ph = pk & 7u; bounce = (pk >> 3) & 0xFFu; oFlags = (pk >> 11) & 3u; sh.kz = (pk >> 13) & 3u; exactSlab = ((pk >> 15) & 1u) != 0;
-  };
-  // Trade (TWO_RAYS): lanes whose active ray does not wait for the wanted phase(s) take any parked ray that
-  // does. Returns the number of rays traded. phB must hold the current phase of this lane's parked slot.
-  auto trade = [&](bool wantT, uint32_t want) -> uint32_t {
-    const bool isFree = wantT ? (ph != PH_NODE && ph != PH_LEAF) : (ph != want);
-    const bool parkedReady = wantT ? (phB == PH_NODE || phB == PH_LEAF) : (phB == want);
-    const unsigned long long mFree = __ballot(isFree), mReady = __ballot(parkedReady);
-    const uint32_t m = min((uint32_t)__popcll(mFree), (uint32_t)__popcll(mReady));
-    if (m > 0) {
-      const unsigned long long lt = (1ull << lane) - 1ull;
-      if (parkedReady) { const uint32_t r = (uint32_t)__popcll(mReady & lt); if (r < m) cq[r] = lane; }
-      __builtin_amdgcn_wave_barrier();
-      if (isFree) {
-        const uint32_t r = (uint32_t)__popcll(mFree & lt);
-        if (r < m) { const uint32_t j = cq[r]; const uint32_t t = ph; swapRays(j); pph[j] = t; }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-    return m;
-  };
-  if (TWO_RAYS) {
-    // park an initial FETCH-state ray so that the first swap brings in a ray that asks for a pixel
-    ph = PH_FETCH;
-    swapRays(lane);       // registers <- uninitialised LDS (ignored: overwritten below), LDS <- FETCH-state ray
-    pph[lane] = PH_FETCH;
-    ph = PH_FETCH; bounce = 0; oFlags = 0; sh.kz = 2; exactSlab = false; hit.leaf = 0xFFFFFFFFu; oLeaf = 0xFFFFFFFFu;
-    __builtin_amdgcn_wave_barrier();
-  }
-
-  // ---- LEAFQ operations ----
-  const uint32_t tid = threadIdx.x;
-  auto fu = [](float f) { return __float_as_uint(f); };
-  auto uf = [](uint32_t u) { return __uint_as_float(u); };
-  // lanes in PH_LEAF publish their request and start waiting
-  auto leafqPush = [&]() {
-    const unsigned long long m = __ballot(ph == PH_LEAF);
-    if (!m) return;
-    if (ph == PH_LEAF) {
-      if (STATS) cs.leaves++;
-      qReq[0 * 256 + tid] = fu(o.x); qReq[1 * 256 + tid] = fu(o.y); qReq[2 * 256 + tid] = fu(o.z);
-      qReq[3 * 256 + tid] = fu(d.x); qReq[4 * 256 + tid] = fu(d.y); qReq[5 * 256 + tid] = fu(d.z);
-      qReq[6 * 256 + tid] = fu(sh.sx); qReq[7 * 256 + tid] = fu(sh.sy); qReq[8 * 256 + tid] = fu(sh.sz);
-      qReq[9 * 256 + tid] = sh.kz; qReq[10 * 256 + tid] = pendLeaf;
-    }
-    const uint32_t first = (uint32_t)__ffsll((long long)m) - 1u;
-    uint32_t base = 0;
-    if (lane == first) base = atomicAdd(&qCtr[1], (uint32_t)__popcll(m));
-    base = __shfl(base, first);
-    if (ph == PH_LEAF) {
-      qRing[(base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & 255u] = tid;
-      ph = PH_WAIT;
-    }
-  };
-  // claim up to 64 requests (a full batch, or whatever is there when `force`) and run them, one per lane
-  auto leafqServe = [&](bool force) -> bool {
-    uint32_t h = 0, want = 0;
-    if (lane == 0) {
-      h = *reinterpret_cast<volatile uint32_t*>(&qCtr[0]);
-      const uint32_t avail = *reinterpret_cast<volatile uint32_t*>(&qCtr[1]) - h;
-      want = avail >= tune.qServe ? min(avail, 64u) : (force ? min(avail, 64u) : 0u);
-      if (want && atomicCAS(&qCtr[0], h, h + want) != h) want = 0;
-    }
-    h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
-    want = (uint32_t)__builtin_amdgcn_readfirstlane((int)want);
-    if (!want) return false;
-    if (STATS) { itL++; lnL += want; }
-    if (lane < want) {
-      const uint32_t slot = (h + lane) & 255u;
-      uint32_t owner;
-      do { owner = qRing[slot]; } while (owner == kLeafQEmpty);      // its producer is between reserve and write
-      qRing[slot] = kLeafQEmpty;
-      const f3 ro = mk(uf(qReq[0 * 256 + owner]), uf(qReq[1 * 256 + owner]), uf(qReq[2 * 256 + owner]));
-      const f3 rd = mk(uf(qReq[3 * 256 + owner]), uf(qReq[4 * 256 + owner]), uf(qReq[5 * 256 + owner]));
-      Shear rs; rs.sx = uf(qReq[6 * 256 + owner]); rs.sy = uf(qReq[7 * 256 + owner]); rs.sz = uf(qReq[8 * 256 + owner]);
-      rs.kz = qReq[9 * 256 + owner];
-      const GLeaf L = sc.leaves[qReq[10 * 256 + owner]];
-      float t, b0 = 0.f, b1 = 0.f, b2 = 0.f;
-      const uint32_t kind = leaf_kind(L);
-      if (kind == LEAF_TRI) {
-        t = intersect_triangle(mk(L.f[0], L.f[1], L.f[2]), mk(L.f[3], L.f[4], L.f[5]), mk(L.f[6], L.f[7], L.f[8]), ro, rs, b0, b1, b2);
-        if (!(t > 0.f && t < kInf)) t = 0.f;                         // Mesh.hpp:93: not a candidate
-      } else if (kind == LEAF_SPHERE) {
-        t = intersect_sphere(L, ro, rd, 0.f);
-      } else {
-        t = intersect_disc(L, ro, rd);
-      }
-      qRes[0 * 256 + owner] = fu(t);
-      if (sc.hasNormals) { qRes[1 * 256 + owner] = fu(b0); qRes[2 * 256 + owner] = fu(b1); qRes[3 * 256 + owner] = fu(b2); }
-      qFlag[owner] = 1u;
-    }
-    return true;
-  };
-  // waiting lanes whose mailbox is full apply the result (CompactBvh.hpp:124) and walk on
-  auto leafqPoll = [&]() {
-    if (ph == PH_WAIT && qFlag[tid] != 0u) {
-      const float t = uf(qRes[0 * 256 + tid]);
-      if (t > 0.f && t < hit.t) {
-        hit.t = t; hit.leaf = pendLeaf;
-        if (sc.hasNormals) { hit.b0 = uf(qRes[1 * 256 + tid]); hit.b1 = uf(qRes[2 * 256 + tid]); hit.b2 = uf(qRes[3 * 256 + tid]); }
-      }
-      qFlag[tid] = 0u;
-      node = node + 1;
-      ph = (node >= numNodes) ? PH_SHADE : PH_NODE;
-    }
-  };
 
   for (;;) {
     // ---------------- FETCH: cheap, always served first ----------------
@@ -348,11 +165,9 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
           pix = entry;
           const mi_trace_result* res = rays + entry;
           prow = res->u; pcol = res->v;
-          if (!TWO_RAYS) {                                                // TWO_RAYS accumulates rgb in memory
-            coldU(0) = entry; coldF(1) = prow; coldF(2) = pcol;
-            if (seg == 0) { coldF(3) = res->rgb.x; coldF(4) = res->rgb.y; coldF(5) = res->rgb.z; }
-            else { coldF(3) = 0.f; coldF(4) = 0.f; coldF(5) = 0.f; }           // a later segment's own partial sum
-          }
+          coldU(0) = entry; coldF(1) = prow; coldF(2) = pcol;
+          if (seg == 0) { coldF(3) = res->rgb.x; coldF(4) = res->rgb.y; coldF(5) = res->rgb.z; }
+          else { coldF(3) = 0.f; coldF(4) = 0.f; coldF(5) = 0.f; }           // a later segment's own partial sum
           rng_seed_pixel_segment(rng, sc.rngSeed, prow, pcol, seg);
           sample = (ex.slotColor ? seg - ex.segBase : seg) << segShift;      // slots are numbered within the launch
           pathStore();                 // (GEN initialises the rest)
@@ -364,59 +179,27 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
     }
 
     // ---------------- vote ----------------
-    if (TWO_RAYS) phB = pph[lane];
     uint32_t cN = (uint32_t)__popcll(__ballot(ph == PH_NODE)), cL = (uint32_t)__popcll(__ballot(ph == PH_LEAF));
     uint32_t cS = (uint32_t)__popcll(__ballot(ph == PH_SHADE)), cG = (uint32_t)__popcll(__ballot(ph == PH_GEN));
-    uint32_t tN = cN, tL = cL, tS = cS, tG = cG;          // populations incl. parked rays
-    if (TWO_RAYS) {
-      if (__ballot(phB == PH_FETCH && ph != PH_FETCH)) {
-        // a parked ray still waits for its first pixel: bring it in, the FETCH service at the loop top serves it
-        if (phB == PH_FETCH && ph != PH_FETCH) { const uint32_t t = ph; swapRays(lane); pph[lane] = t; }
-        __builtin_amdgcn_wave_barrier();
-        continue;
-      }
-      tN += (uint32_t)__popcll(__ballot(phB == PH_NODE)); tL += (uint32_t)__popcll(__ballot(phB == PH_LEAF));
-      tS += (uint32_t)__popcll(__ballot(phB == PH_SHADE)); tG += (uint32_t)__popcll(__ballot(phB == PH_GEN));
-    }
-    if (LEAFQ) {
-      const uint32_t cW = (uint32_t)__popcll(__ballot(ph == PH_WAIT));
-      if (cW > 0) {
-        if ((tN | tL | tS | tG) == 0) {
-          // nothing to run but rays waiting for primitive tests: serve whatever is queued (possibly our own)
-          if (!leafqServe(true)) __builtin_amdgcn_s_sleep(1);
-          leafqPoll();
-          continue;
-        }
-        leafqServe(false);
-        leafqPoll();
-        cN = tN = (uint32_t)__popcll(__ballot(ph == PH_NODE)); cS = tS = (uint32_t)__popcll(__ballot(ph == PH_SHADE));
-      }
-    }
-    if ((tN | tL | tS | tG) == 0) break;            // every ray DONE (FETCH lanes were just served)
+    if ((cN | cL | cS | cG) == 0) break;            // every ray DONE (FETCH lanes were just served)
     // Top-level vote: TRAVERSE (the NODE and LEAF populations together) against SHADE and GEN, by weighted
     // population (a phase cannot use more than 64 lanes). Inside TRAVERSE a two-way mini-vote (two ballots)
     // alternates box tests and primitive tests, so the expensive vote is only paid when the wave leaves traversal.
     // run: 0 = TRAVERSE, 2 = SHADE, 3 = GEN
     uint32_t run;
     {
-      const uint32_t pT = min(tN + tL, 64u), pS = min(tS, 64u), pG = min(tG, 64u);
+      const uint32_t pT = cN + cL, pS = cS, pG = cG;
       const uint32_t wT = pT * 4u, wS = pS * tune.shadeAt, wG = pG * tune.genAt;
       if (pT > 0 && wT >= max(wS, wG)) run = 0;
       else run = (wS >= wG) ? 2 : 3;
     }
-    if (TWO_RAYS) {
-      trade(run == 0, run == 2 ? (uint32_t)PH_SHADE : (uint32_t)PH_GEN);
-      cN = (uint32_t)__popcll(__ballot(ph == PH_NODE)); cL = (uint32_t)__popcll(__ballot(ph == PH_LEAF));
-      cS = (uint32_t)__popcll(__ballot(ph == PH_SHADE)); cG = (uint32_t)__popcll(__ballot(ph == PH_GEN));
-    }
-
     if (run == 0) {
       // ---------------- TRAVERSE: NODE and LEAF steps under a two-way mini-vote ----------------
       const unsigned long long tq0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
       if (tune.prio == 1) __builtin_amdgcn_s_setprio(1); else if (tune.prio == 2) __builtin_amdgcn_s_setprio(0);
       const uint32_t startT = cN + cL;
       uint32_t steps = 0;
-      // lanes only change rays in SHADE/GEN (or in a trade), so "some lane needs the literal box test" is a
+      // lanes only change rays in SHADE/GEN, so "some lane needs the literal box test" is a
       // per-burst fact
       bool anyExact = __ballot(exactSlab) != 0ull;
       // One box test of a lane that is in the NODE phase; returns whether the lane is still in it afterwards, so that
@@ -442,7 +225,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
           const float az = (nd.minz - o.z) * inv.z, bz = (nd.maxz - o.z) * inv.z;
           float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
           float t1 = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * kSlabScale, hit.t);
-          if (TWO_RAYS ? (__ballot(exactSlab) != 0ull) : anyExact) {
+          if (anyExact) {
             if (exactSlab) {
               t0 = 0.f; t1 = hit.t;
               { float tmin = ax, tmax = bx; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
@@ -465,36 +248,31 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
       auto nodeStep = [&]() { if (ph == PH_NODE) (void)nodeBody(); };
       for (;;) {
         const uint32_t stay = cN;
-        if (LEAFQ ? (cN > 0) : (cN * 4u >= cL * tune.leafAt && cN > 0)) {
+        if (cN * 4u >= cL * tune.leafAt && cN > 0) {
           // NODE: one box test per lane. With many lanes in the walk two box tests run back to back before the wave
           // votes again (tune.dbl): a vote costs a ballot-popcount-branch chain whose latency the second test hides;
           // lanes that reached a leaf in the first simply sit the second out.
           if (STATS) { itN++; lnN += stay; }
-          if (LEAFQ || TWO_RAYS) nodeStep();
-          else {
-            const uint32_t extra = min(stay / tune.dbl, tune.maxExtra);       // wave-uniform
-            if (STATS) {
-              // instrumented build: the same tests, one exec region each, counted
-              nodeStep();
-              for (uint32_t e = 0; e < extra; ++e) { itN++; lnN += (uint32_t)__popcll(__ballot(ph == PH_NODE)); nodeStep(); }
-            } else if (ph == PH_NODE) {
-              // spelled out rather than looped: straight-line code, and each further test runs under the previous
-              // one's "still walking" condition instead of re-reading `ph`
-              bool go = nodeBody();
-              if (extra >= 1 && go) { go = nodeBody();
-                if (extra >= 2 && go) { go = nodeBody();
-                  if (extra >= 3 && go) { go = nodeBody();
-                    if (extra >= 4 && go) { go = nodeBody();
-                      if (extra >= 5 && go) (void)nodeBody();
-                    }
+          const uint32_t extra = min(stay / tune.dbl, tune.maxExtra);       // wave-uniform
+          if (STATS) {
+            // instrumented build: the same tests, one exec region each, counted
+            nodeStep();
+            for (uint32_t e = 0; e < extra; ++e) { itN++; lnN += (uint32_t)__popcll(__ballot(ph == PH_NODE)); nodeStep(); }
+          } else if (ph == PH_NODE) {
+            // spelled out rather than looped: straight-line code, and each further test runs under the previous
+            // one's "still walking" condition instead of re-reading `ph`
+            bool go = nodeBody();
+            if (extra >= 1 && go) { go = nodeBody();
+              if (extra >= 2 && go) { go = nodeBody();
+                if (extra >= 3 && go) { go = nodeBody();
+                  if (extra >= 4 && go) { go = nodeBody();
+                    if (extra >= 5 && go) (void)nodeBody();
                   }
                 }
               }
             }
-            steps += extra;
           }
-        } else if (LEAFQ) {
-          // (LEAFQ housekeeping follows the NODE step below)
+          steps += extra;
         } else {
           // LEAF: one primitive test per lane
           if (STATS) { itL++; lnL += cL; }
@@ -520,7 +298,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
           }
           // every lane that waited for a primitive test is walking again: the next vote would pick NODE anyway,
           // so a box test follows at once (tune.leafThenNode) and the vote after it sees its outcome
-          if (!TWO_RAYS && tune.leafThenNode) {
+          if (tune.leafThenNode) {
             if (STATS) { itN++; lnN += (uint32_t)__popcll(__ballot(ph == PH_NODE)); }
             nodeStep();
             ++steps;
@@ -528,24 +306,6 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
         }
         cN = (uint32_t)__popcll(__ballot(ph == PH_NODE));
         cL = (uint32_t)__popcll(__ballot(ph == PH_LEAF));
-        if (LEAFQ) {
-          // hand the LEAF lanes' primitive tests to the workgroup's queue once a few have gathered (or nothing else
-          // is left to do), run a batch if the queue holds one, and let waiting lanes pick up finished tests
-          if (cL >= tune.qPush || (cL > 0 && cN == 0)) { leafqPush(); leafqServe(false); cL = 0; }
-          if (__ballot(ph == PH_WAIT)) {
-            if (cN == 0) leafqServe(true);
-            leafqPoll();
-            cN = (uint32_t)__popcll(__ballot(ph == PH_NODE));
-          }
-        }
-        if (TWO_RAYS && 64u - (cN + cL) >= tune.tradeAt) {
-          // enough idle lanes: refill them from the parked rays that are mid-traversal
-          phB = pph[lane];
-          if ((uint32_t)__popcll(__ballot(phB == PH_NODE || phB == PH_LEAF)) >= tune.tradeAt / 2u && trade(true, 0u) > 0) {
-            cN = (uint32_t)__popcll(__ballot(ph == PH_NODE));
-            cL = (uint32_t)__popcll(__ballot(ph == PH_LEAF));
-          }
-        }
         if (++steps >= tune.burst || (cN + cL) * 8u < startT * tune.keep8 || (cN + cL) == 0) break;
       }
       if (tune.prio == 1) __builtin_amdgcn_s_setprio(0); else if (tune.prio == 2) __builtin_amdgcn_s_setprio(1);
@@ -562,7 +322,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
         if (hit.leaf != 0xFFFFFFFFu) {
           const GLeaf L = sc.leaves[hit.leaf];
           hit.geomID = leaf_geom(L);
-          if (TWO_RAYS) { oLeaf = hit.leaf; oTmax = hit.t; } else { coldU(6) = hit.leaf; coldF(7) = hit.t; }
+          coldU(6) = hit.leaf; coldF(7) = hit.t;
           o = o + d * hit.t;                                          // updateHit, Render.hpp:15-23
           nrm = hit_normal(sc, hit, o);
           const mi_material mat = sc.materials[L.matIndex];           // = materials[matIDs[geomID]]
@@ -583,12 +343,12 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
             d = nd2;
             if (refracted) tp = tp * albedo;
           } else {
-            if (TWO_RAYS) { mi_trace_result* res = rays + getPix(); const float qn = __builtin_nanf(""); res->rgb = {res->rgb.x * qn, res->rgb.y * qn, res->rgb.z * qn}; }
-            else { const float qn = __builtin_nanf(""); coldF(3) = coldF(3) * qn; coldF(4) = coldF(4) * qn; coldF(5) = coldF(5) * qn; }
+            const float qn = __builtin_nanf("");
+            coldF(3) = coldF(3) * qn; coldF(4) = coldF(4) * qn; coldF(5) = coldF(5) * qn;
             oFlags |= MI_FLAG_ERROR;
           }
         } else {
-          if (TWO_RAYS) oTmax = kInf; else coldF(7) = kInf;
+          coldF(7) = kInf;
           oFlags |= MI_FLAG_ESCAPED;
           terminated = true;
         }
@@ -607,8 +367,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
             envRay = (oFlags & MI_FLAG_ESCAPED) != 0;
             envSlot = (uint32_t)q;
             if (!envRay) ex.u[q] = -1.f;
-          } else if (TWO_RAYS) { const mi_vec3 acc = res->rgb; res->rgb = {acc.x + color.x, acc.y + color.y, acc.z + color.z}; }
-          else { coldF(3) = coldF(3) + color.x; coldF(4) = coldF(4) + color.y; coldF(5) = coldF(5) + color.z; }
+          } else { coldF(3) = coldF(3) + color.x; coldF(4) = coldF(4) + color.y; coldF(5) = coldF(5) + color.z; }
           ++paths;
           ++sample;
           const bool more = segd ? ((sample & segMask) != 0u && sample < spp) : (sample < spp);
@@ -622,17 +381,17 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
             ph = PH_FETCH;
           } else {
             // pixel complete: rgb sum + the LAST sample's hit record
-            if (ex.segPart && !TWO_RAYS) {
+            if (ex.segPart) {
               float* part = ex.segPart + 3 * ((size_t)(((sample - 1u) >> segShift) - ex.segBase) * n + pixNow);
               part[0] = coldF(3); part[1] = coldF(4); part[2] = coldF(5);
             } else
-            if (!TWO_RAYS && !ex.slotColor) res->rgb = {coldF(3), coldF(4), coldF(5)};
+            if (!ex.slotColor) res->rgb = {coldF(3), coldF(4), coldF(5)};
             uint32_t oPrim = MI_INVALID_PRIM, oGeom = MI_INVALID_GEOM;
-            const uint32_t lastLeaf = TWO_RAYS ? oLeaf : coldU(6);
+            const uint32_t lastLeaf = coldU(6);
             if (lastLeaf != 0xFFFFFFFFu) { const GLeaf LL = sc.leaves[lastLeaf]; oPrim = LL.primID; oGeom = leaf_geom(LL); }
             mi_hit_record hr;
             hr.r.origin = {o.x, o.y, o.z}; hr.r.t_min = 0.f;
-            hr.r.direction = {d.x, d.y, d.z}; hr.r.t_max = TWO_RAYS ? oTmax : coldF(7);
+            hr.r.direction = {d.x, d.y, d.z}; hr.r.t_max = coldF(7);
             hr.prim_id = oPrim;
             hr.normal = {nrm.x, nrm.y, nrm.z};
             hr.throughput = {tp.x, tp.y, tp.z};
@@ -683,15 +442,14 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && TWO_RAYS) ? 4 : (BLOCK
       const unsigned long long tq2 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
       if (ph == PH_GEN) {
         pathLoad();
-        if (TWO_RAYS) { prow = rays[pix].u; pcol = rays[pix].v; }     // not part of the parked state
-        else { prow = coldF(1); pcol = coldF(2); }
+        prow = coldF(1); pcol = coldF(2);
         float g0, g1;
         rng_gauss2(rng, sinTbl, g0, g1);
         const float jr = prow + sc.antiAliasScale * g0, jc = pcol + sc.antiAliasScale * g1;
         d = pixel_to_ray_dir(jc, jr, sc.imageWidth, sc.imageHeight, sc.tanTheta);
         o = mk(0.f, 0.f, 0.f);
         nrm = mk(0.f, 0.f, 1.f);                         // HitRecord ctor, geometry.hpp:236-242
-        if (TWO_RAYS) { oLeaf = 0xFFFFFFFFu; oTmax = kInf; } else { coldU(6) = 0xFFFFFFFFu; coldF(7) = kInf; }
+        coldU(6) = 0xFFFFFFFFu; coldF(7) = kInf;
         oFlags = 0;
         tp = mk(1.f, 1.f, 1.f);
         color = mk(0.f, 0.f, 0.f);

@@ -188,7 +188,7 @@ def main():
         d.roulette_start_depth = int(rng.integers(0, 7))
         mode = irl.MODE_PATH_TRACE if rng.random() < 0.8 else irl.MODE_SHADOW_TRACE
         d.path_trace = 1 if mode == irl.MODE_PATH_TRACE else 0
-        kernel = str(rng.choice(["0", "1", "1", "1", "2", "3", "4"]))
+        kernel = str(rng.choice(["0", "1", "1", "1", "2"]))
         waves = str(rng.choice(["4", "5"]))
         os.environ["MI_RAYLIB_KERNEL"] = kernel; os.environ["MI_RAYLIB_WAVES"] = waves
         batch = int(rng.integers(1, 4000)) if rng.random() < 0.25 else 0

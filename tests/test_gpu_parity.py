@@ -83,12 +83,12 @@ def test_traversal_visits_exactly_the_reference_nodes(scenes, monkeypatch):
 # ------------------------------------------------------------------------------------------------------
 # path trace: rgb sums + last-sample hit records, per-pixel RNG streams
 # ------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("kernel", ["0", "1", "1w4", "2", "3", "4", "4w4"])
+@pytest.mark.parametrize("kernel", ["0", "1", "1w4", "2"])
 @pytest.mark.parametrize("name,size,spp", [("box-simple", 128, 32), ("box", 160, 24), ("spheres", 128, 32)])
 def test_path_trace_bit_exact(scenes, name, size, spp, kernel, monkeypatch):
     """kernel 0 = nested-loop kernel, 1 = phase-scheduled persistent kernel, 2 = the same with the BVH
-    prefix staged in LDS, 3 = two rays per lane (second one parked in LDS); 1 is built for 5 waves per SIMD
-    (default) and for 4 ("1w4"); 4 = primitive tests pooled across the workgroup through an LDS queue. All of them must reproduce the oracle bit for bit."""
+    prefix staged in LDS; 1 is built for 5 waves per SIMD (default) and for 4 ("1w4"). All of them must reproduce
+    the oracle bit for bit."""
     monkeypatch.setenv("MI_RAYLIB_KERNEL", kernel[0])
     monkeypatch.setenv("MI_RAYLIB_WAVES", "4" if kernel.endswith("w4") else "5")
     s = scenes[name]
@@ -617,14 +617,14 @@ def test_randomised_render_parameters_against_oracle(scenes):
         d.set_image(96, 64); d.anti_alias_scale = 0.25; d.max_path_length = 10; d.roulette_start_depth = 3; d.rng_seed = 1442
 
 
-@pytest.mark.parametrize("kernel,spp", [("0", 300), ("1", 300), ("2", 300), ("3", 300), ("4", 300), ("0", 700), ("1", 700), ("3", 700)])
+@pytest.mark.parametrize("kernel,spp", [("0", 300), ("1", 300), ("2", 300), ("0", 700), ("1", 700), ("2", 700)])
 def test_segmented_pixels_bit_exact(scenes, kernel, spp, monkeypatch):
     """More samples per pixel than one segment holds: the pixel is traced as segments (about sixteen per pixel, 4 to 64
     samples long), each with its own RNG stream and partial rgb sum, added in segment order.
     300 spp = nine full 32-sample segments + one of 12; 700 spp = ten full 64-sample segments + one of 60; the incoming
     rgb is non-zero (segment 0 accumulates onto it). Every kernel variant - the persistent kernel traces (pixel,
-    segment) work atoms, the nested-loop kernel loops over the segments in one thread, the two-rays variant falls
-    back to it - must reproduce the oracle bit for bit; so must a batched render (both pipeline slots, each with its own partial-sum buffer)."""
+    segment) work atoms, the nested-loop kernel loops over the segments in one thread - must reproduce the oracle bit
+    for bit; so must a batched render (both pipeline slots, each with its own partial-sum buffer)."""
     monkeypatch.setenv("MI_RAYLIB_KERNEL", kernel)
     s = scenes["box"]; d = s.desc
     d.set_image(72, 40); d.samples_per_pixel = spp; d.path_trace = 1
