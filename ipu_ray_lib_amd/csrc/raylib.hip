@@ -268,7 +268,7 @@ void ensureScratch(mi_scene& S, size_t n) {
 }
 
 bool g_fullStats = false;
-WaveTune g_tune = {5, 16, 24, 48, 3};
+WaveTune g_tune = {8, 16, 24, 48, 3};
 int g_kernelChoice = 1;           // 0 = nested-loop kernel, 1 = wavefront (global nodes), 2 = wavefront + LDS-staged nodes
 int g_wavesPerSimd = 5;          // MI_RAYLIB_WAVES=4: the 108-VGPR build of the default kernel (4 waves per SIMD)
 
@@ -422,7 +422,7 @@ int mi_scene_create(const mi_scene_desc* desc, mi_scene** out) {
     S->params.spheres = nullptr; S->params.discs = nullptr;
     if (const char* e = getenv("MI_RAYLIB_FULL_STATS")) g_fullStats = (e[0] == '1');
     if (const char* e = getenv("MI_RAYLIB_TUNE")) {      // leafAt,shadeAt,genAt[,burst,keep8,dbl,maxExtra,leafThenNode,prio]
-      unsigned a, b, c, dd = 48, k8 = 3, db = 6, mx = 5, ln = 1, pr = 1;
+      unsigned a, b, c, dd = 48, k8 = 3, db = 4, mx = 5, ln = 1, pr = 1;
       if (sscanf(e, "%u,%u,%u,%u,%u,%u,%u,%u,%u", &a, &b, &c, &dd, &k8, &db, &mx, &ln, &pr) >= 3) g_tune = {a, b, c, dd, k8, db ? db : 65, mx, ln, pr};
     }
     if (const char* e = getenv("MI_RAYLIB_WAVES")) g_wavesPerSimd = (e[0] == '4') ? 4 : 5;

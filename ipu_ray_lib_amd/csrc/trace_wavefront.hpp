@@ -27,7 +27,7 @@ namespace mi {
 enum : uint32_t { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_GEN = 3, PH_FETCH = 4, PH_DONE = 5 };
 
 // Scheduling weights (quarter units, NODE/TRAVERSE weigh 4) and traversal-burst limits; the defaults
-// {5, 16, 24, 48, 3} are the measured optimum on the box scene (+-2 % plateau):
+// {8, 16, 24, 48, 3} (dbl 4) are the measured optimum on the box scene (+-1 % plateau):
 //   leafAt   inside a traversal burst, LEAF runs when cL*leafAt > cN*4
 //   shadeAt, genAt   top-level vote: SHADE/GEN run when their weighted population exceeds (cN+cL)*4
 //   burst    at most this many NODE/LEAF steps before the wave re-votes
@@ -36,7 +36,7 @@ enum : uint32_t { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_GEN = 3, PH_FETCH =
 //   leafThenNode    a box test follows every LEAF turn at once
 //   prio     1: waves run their traversal turns at s_setprio 1 (short dependent steps win VALU arbitration over
 //            another wave's long SHADE/GEN blocks: +1 %), 0: no priorities
-struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, dbl = 6, maxExtra = 5, leafThenNode = 1, prio = 1; };
+struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, dbl = 4, maxExtra = 5, leafThenNode = 1, prio = 1; };
 
 // Per-launch extras for renders with the NIF environment. The reference traces ONE sample, evaluates the
 // environment for the rays that escaped, adds it, and repeats (src/IpuScene.cpp:571-583). One sample per launch
