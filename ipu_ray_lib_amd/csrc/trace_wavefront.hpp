@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
       bool anyExact = __ballot(exactSlab) != 0ull;
       // One box test of a lane that is in the NODE phase; returns whether the lane is still in it afterwards, so that
       // back-to-back tests narrow the exec mask from that condition directly instead of re-reading `ph`.
-      auto nodeBody = [&]() -> bool {
+      auto nodeBodyT = [&](auto exactTag) -> bool {
         {
           GNode nd;
           // (uniform base + 32-bit byte offset: the load takes the scalar-base form, one shift instead of 64-bit address math)
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
           const float az = (nd.minz - o.z) * inv.z, bz = (nd.maxz - o.z) * inv.z;
           float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
           float t1 = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * kSlabScale, hit.t);
-          if (anyExact) {
+          if constexpr (decltype(exactTag)::value) {
             if (exactSlab) {
               t0 = 0.f; t1 = hit.t;
               { float tmin = ax, tmax = bx; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
@@ -245,7 +245,8 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
           return true;
         }
       };
-      auto nodeStep = [&]() { if (ph == PH_NODE) (void)nodeBody(); };
+      auto nodeBody = [&]() -> bool { return nodeBodyT(std::false_type{}); };               // the common case: no lane needs the literal test
+      auto nodeStep = [&]() { if (ph == PH_NODE) (void)(anyExact ? nodeBodyT(std::true_type{}) : nodeBodyT(std::false_type{})); };
       for (;;) {
         const uint32_t stay = cN;
         if (cN * 4u >= cL * tune.leafAt && cN > 0) {
@@ -258,6 +259,10 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
             // instrumented build: the same tests, one exec region each, counted
             nodeStep();
             for (uint32_t e = 0; e < extra; ++e) { itN++; lnN += (uint32_t)__popcll(__ballot(ph == PH_NODE)); nodeStep(); }
+          } else if (anyExact) {
+            // (a lane of this burst needs the literal compare/select box test: the rolled form carries it)
+            nodeStep();
+            for (uint32_t e = 0; e < extra; ++e) nodeStep();
           } else if (ph == PH_NODE) {
             // spelled out rather than looped: straight-line code, and each further test runs under the previous
             // one's "still walking" condition instead of re-reading `ph`
