@@ -235,8 +235,8 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
           }
           const bool boxHit = !(t0 > t1);
           const bool isLeaf = nd.geomID != 0xFFFFu;
+          pendLeaf = nd.link;          // only read while the lane is in PH_LEAF; assigned for every lane so that no merge copy is needed
           if (boxHit && isLeaf) {
-            pendLeaf = nd.link;
             ph = PH_LEAF;
             return false;
           }
