@@ -151,7 +151,11 @@ int mi_render(mi_scene* scene, int mode, mi_trace_result* rays, size_t n, mi_ray
 
 /* Same operation on a DEVICE-resident ray stream (hipMalloc'ed / torch tensor memory), enqueued
  * on `hip_stream` (a hipStream_t passed as void*; NULL = the null stream). Asynchronous: returns
- * after enqueue. This is the entry bench.py times (inputs already resident in HBM). */
+ * after enqueue. This is the entry bench.py times (inputs already resident in HBM).
+ * Threading: a scene is thread-compatible (calls on ONE scene must not overlap in time on the host; different
+ * scenes are independent). Launches of one scene enqueued on different streams own separate work counters and
+ * partial-sum buffers and may execute concurrently; renders with a NIF environment share the scene's slot scratch
+ * and are chained with an event, so they execute one after the other whatever streams they were enqueued on. */
 int mi_render_device(mi_scene* scene, int mode, void* d_rays, size_t n, void* hip_stream);
 
 /* Replaces: IpuScene::getTraceTimeSecs (IpuScene.hpp:55). Wall time of the last mi_render. */
@@ -194,6 +198,15 @@ int mi_scene_set_max_nif_batch(mi_scene* scene, size_t rays_per_batch);
  * raysPerWorker), pipelines their upload / trace / download on two HIP streams and calls the ray callback once
  * per finished batch, in batch order. 0 (default) = one batch. Results do not depend on the batch size. */
 int mi_scene_set_ray_batch(mi_scene* scene, size_t rays_per_batch);
+
+/* Kernel selection / tuning of ONE scene (no reference counterpart; the nearest is the reference's per-run
+ * RuntimeConfig + codelet build flags, trace.cpp:297-309). Every scene carries its own copy: defaults, overridden
+ * by the MI_RAYLIB_* environment variables as they stand when the scene is created, then by this call. Keys:
+ * "kernel" 0|1|2 (nested-loop / phase-scheduled / phase-scheduled + LDS-staged nodes), "waves" 4|5, "full_stats" 0|1
+ * (instrumented kernels: node / leaf-test counters and phase occupancy), "tune" "leafAt,shadeAt,genAt[,...]",
+ * "tiles" 0|1, "seg_budget_kb" N, "nif_spl" N (NIF samples per launch), "nif_shape" w6|t6|t4, "pin" 0|1.
+ * None of them changes a result bit. Returns MI_ERR_INVALID_ARG for an unknown key or unparsable value. */
+int mi_scene_set_option(mi_scene* scene, const char* key, const char* value);
 
 /* The NIF environment evaluated stand-alone on device arrays: for i<n, bgr[i*3..] =
  * decode(MLP(fourier(u[i], v[i]))). Replaces NifModel::buildInference's execModel

@@ -173,6 +173,7 @@ def device_lib() -> C.CDLL:
         lib.mi_scene_set_max_nif_batch.argtypes = [C.c_void_p, C.c_size_t]
         lib.mi_scene_set_ray_batch.argtypes = [C.c_void_p, C.c_size_t]
         lib.mi_nif_infer_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.mi_scene_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         _device = lib
     return _device
 
@@ -365,6 +366,11 @@ class IpuScene:
 
     def setRayBatch(self, rays_per_batch: int):
         _check_dev(self._lib.mi_scene_set_ray_batch(self._h, int(rays_per_batch)))
+
+    def set_option(self, key: str, value) -> "IpuScene":
+        """Kernel selection / tuning of THIS scene (mi_scene_set_option); never changes a result bit."""
+        _check_dev(self._lib.mi_scene_set_option(self._h, key.encode(), str(value).encode()))
+        return self
 
     def getTraceTimeSecs(self) -> float:
         return float(self._lib.mi_trace_time_secs(self._h))

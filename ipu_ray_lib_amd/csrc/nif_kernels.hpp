@@ -99,7 +99,7 @@ struct NifDevice {
     NifParams P{};
     P.numLayers = numLayers; P.embedDim = embedDim; P.featBase = featBase;
     const uint32_t kPadMax = ((featBase + F + 31u) & ~31u);
-    P.stride = kPadMax + 16; if (const char* e = getenv("MI_RAYLIB_NIF_PAD")) P.stride = kPadMax + (uint32_t)atoi(e);
+    P.stride = kPadMax + 16;
                      // +16 halves: rows start 8 banks apart -> the ds_read_b128 lane groups
                                                   // (rows l&15, k-chunk l>>4) hit 16 disjoint 4-bank slots (measured: +8 gave 2-way conflicts)
     P.maxValue = maxValue; P.mean[0] = mean[0]; P.mean[1] = mean[1]; P.mean[2] = mean[2]; P.logTonemap = logTonemap;
@@ -400,16 +400,15 @@ __global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : 1) nif_ml
 
 // bgrOut: result of row r at bgrOut[3r..] - or, with `scatter`, at bgrOut[3*idx[r]..] (the row's own slot)
 inline void nif_launch_mlp(const NifDevice& nif, const float* u, const float* v, const uint32_t* idx, const uint32_t* countPtr,
-                           uint32_t numRows, float* bgrOut, mi_trace_result* rays, hipStream_t stream, bool scatter = false) {
+                           uint32_t numRows, float* bgrOut, mi_trace_result* rays, hipStream_t stream, bool scatter = false, uint32_t shape = 0) {
   if (numRows == 0) return;
   uint32_t maxTiles = 1;
   for (uint32_t l = 0; l < nif.p.numLayers; ++l) maxTiles = std::max(maxTiles, nif.p.layers[l].nTiles / 4);
-  // shape: MT ray tiles per wave x RG row groups. MI_RAYLIB_NIF_SHAPE=w6|t6|t4 overrides the default (w6).
+  // shape: MT ray tiles per wave x RG row groups. Scene option "nif_shape" = w6|t6|t4 (`shape` 0|1|2) overrides the default (w6).
   // (4 waves x 64 / 128 / 192 rays were measured too - DESIGN.md §6 - and are not kept: at their register
   // pressure hipcc spills around the hand-counted asm loads, which the .s audit in tests/ flags.)
-  const char* shapeEnv = getenv("MI_RAYLIB_NIF_SHAPE");
   uint32_t mt = 6, rg = 1;
-  if (shapeEnv && shapeEnv[0] == 't') { rg = 2; mt = (shapeEnv[1] == '6') ? 6 : 4; }
+  if (shape != 0) { rg = 2; mt = (shape == 1) ? 6 : 4; }
   if (!(mt == 4 && rg == 2) && ((size_t)16 * mt * rg * nif.p.stride * sizeof(_Float16) > kNifMaxLdsBytes || maxTiles > 5)) { mt = 4; rg = 2; }
   auto launch = [&](auto kern, uint32_t rowsPerPass, uint32_t threads) {
     const size_t lds = (size_t)rowsPerPass * nif.p.stride * sizeof(_Float16);
@@ -475,21 +474,21 @@ __global__ void __launch_bounds__(256) nif_segment_roll_kernel(mi_trace_result* 
 }
 
 // mi_nif_infer_device: every row is evaluated (no compaction)
-inline void nif_infer(NifDevice& nif, const float* d_u, const float* d_v, float* d_bgr, size_t n, size_t maxBatch, hipStream_t stream) {
+inline void nif_infer(NifDevice& nif, const float* d_u, const float* d_v, float* d_bgr, size_t n, size_t maxBatch, hipStream_t stream, uint32_t shape = 0) {
   const size_t chunk = maxBatch ? maxBatch : n;
   for (size_t off = 0; off < n; off += chunk) {
     const size_t cnt = (n - off < chunk) ? (n - off) : chunk;
-    nif_launch_mlp(nif, d_u + off, d_v + off, nullptr, nullptr, (uint32_t)cnt, d_bgr + 3 * off, nullptr, stream);
+    nif_launch_mlp(nif, d_u + off, d_v + off, nullptr, nullptr, (uint32_t)cnt, d_bgr + 3 * off, nullptr, stream, false, shape);
   }
 }
 
 // One sample's environment pass over the whole ray stream (src/IpuScene.cpp:571-583)
 inline void nif_env_pass(NifDevice& nif, mi_trace_result* d_rays, uint32_t n, float azimuthRadians, float* d_u, float* d_v,
-                         float* d_bgr, size_t /*maxBatch*/, hipStream_t stream) {
+                         float* d_bgr, size_t /*maxBatch*/, hipStream_t stream, uint32_t shape = 0) {
   nif.ensureIndex(n);
   (void)hipMemsetAsync(nif.d_count, 0, sizeof(uint32_t), stream);
   hipLaunchKernelGGL(escaped_uv_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_rays, n, azimuthRadians, d_u, d_v, nif.d_index, nif.d_count);
-  nif_launch_mlp(nif, d_u, d_v, nif.d_index, nif.d_count, n, nullptr, d_rays, stream);
+  nif_launch_mlp(nif, d_u, d_v, nif.d_index, nif.d_count, n, nullptr, d_rays, stream, false, shape);
 }
 
 }  // namespace mi

@@ -72,14 +72,70 @@ const float* hostSinTable() {
 
 }  // namespace
 
+// Kernel selection and tuning of ONE scene: defaults, overridden by the MI_RAYLIB_* environment variables as they
+// stand when the scene is created (read once, into the scene) and by mi_scene_set_option afterwards. Nothing here is
+// process-global: creating or tuning scene B never changes what scene A launches.
+struct SceneOptions {
+  bool fullStats = false;          // MI_RAYLIB_FULL_STATS / "full_stats": instrumented kernel variants (node/leaf counters, phase occupancy)
+  WaveTune tune = {8, 16, 24, 48, 3};
+  int kernelChoice = 1;            // MI_RAYLIB_KERNEL / "kernel": 0 = nested-loop kernel, 1 = wavefront (global nodes), 2 = wavefront + LDS-staged nodes
+  int wavesPerSimd = 5;            // MI_RAYLIB_WAVES / "waves": 4 = the 108-VGPR build of the default kernel
+  bool tiles = true;               // MI_RAYLIB_NO_TILES / "tiles": walk row-structured streams in 8x8 pixel tiles
+  size_t segBudgetKb = (size_t)8 * 1024 * 1024;   // MI_RAYLIB_SEG_BUDGET_KB / "seg_budget_kb": partial-sum buffer budget per launch
+  uint32_t nifSamplesPerLaunch = 0;               // MI_RAYLIB_NIF_SPL / "nif_spl": 0 = default (128, memory permitting)
+  bool pin = true;                 // MI_RAYLIB_PIN / "pin": page-lock the caller's stream for the duration of mi_render
+  uint32_t nifShape = 0;           // MI_RAYLIB_NIF_SHAPE / "nif_shape": 0 = w6 (default), 1 = t6, 2 = t4
+
+  bool set(const std::string& key, const char* v) {
+    if (!v) return false;
+    if (key == "full_stats") fullStats = v[0] == '1';
+    else if (key == "kernel") kernelChoice = (v[0] == '0') ? 0 : (v[0] == '2') ? 2 : 1;
+    else if (key == "waves") wavesPerSimd = (v[0] == '4') ? 4 : 5;
+    else if (key == "tiles") tiles = v[0] != '0';
+    else if (key == "seg_budget_kb") segBudgetKb = std::max<size_t>((size_t)strtoull(v, nullptr, 10), 1);
+    else if (key == "nif_spl") nifSamplesPerLaunch = (uint32_t)atoi(v);
+    else if (key == "pin") pin = v[0] != '0';
+    else if (key == "nif_shape") nifShape = (v[0] == 't') ? ((v[1] == '6') ? 1u : 2u) : 0u;
+    else if (key == "tune") {      // leafAt,shadeAt,genAt[,burst,keep8,dbl,maxExtra,leafThenNode,prio]
+      unsigned a, b, c, dd = 48, k8 = 3, db = 4, mx = 5, ln = 1, pr = 1;
+      if (sscanf(v, "%u,%u,%u,%u,%u,%u,%u,%u,%u", &a, &b, &c, &dd, &k8, &db, &mx, &ln, &pr) < 3) return false;
+      tune = {a, b, c, dd, k8, db ? db : 65, mx, ln, pr};
+    } else return false;
+    return true;
+  }
+  void fromEnvironment() {
+    static const char* const map[][2] = {{"MI_RAYLIB_FULL_STATS", "full_stats"}, {"MI_RAYLIB_KERNEL", "kernel"}, {"MI_RAYLIB_WAVES", "waves"},
+                                         {"MI_RAYLIB_SEG_BUDGET_KB", "seg_budget_kb"}, {"MI_RAYLIB_NIF_SPL", "nif_spl"}, {"MI_RAYLIB_PIN", "pin"},
+                                         {"MI_RAYLIB_NIF_SHAPE", "nif_shape"}, {"MI_RAYLIB_TUNE", "tune"}};
+    for (const auto& m : map) if (const char* e = getenv(m[0])) (void)set(m[1], e);
+    if (getenv("MI_RAYLIB_NO_TILES")) tiles = false;
+  }
+};
+
+// What one in-flight path-trace launch owns besides the ray stream: its work counter and the partial-sum buffer of
+// segmented pixels. One per HIP stream the scene has been rendered on, so launches of one scene that are enqueued on
+// different streams (mi_render's two pipeline slots, or a caller's own streams through mi_render_device) never share
+// them. Renders with a NIF environment additionally share the scene's slot scratch and are therefore chained with an
+// event (nifDone): they may be enqueued on any streams but execute one after the other.
+struct LaunchSlot {
+  hipStream_t stream = nullptr;
+  uint32_t* d_workCounter = nullptr;
+  float* d_segPart = nullptr; size_t segPartFloats = 0;     // [segments][n][3]
+};
+
 struct mi_scene {
   int device = 0;
   mi_scene_desc params{};            // scalar parameters only (pointers nulled)
   DeviceScene ds{};
+  SceneOptions opt;
   std::vector<void*> allocations;
   unsigned long long* d_counters = nullptr;
-  uint32_t* d_workCounter = nullptr;
-  float* d_segPart[2] = {nullptr, nullptr}; size_t segPartFloats[2] = {0, 0};     // partial rgb sums of segmented pixels, [segments][n][3], one buffer per pipeline slot
+  std::vector<LaunchSlot> slots;
+  bool ldsAttrSet[2] = {false, false};   // kernel 2's dynamic-LDS opt-in (plain / instrumented build), per scene and so per device: function attributes are per device
+  hipEvent_t nifDone = nullptr; bool nifPending = false;
+  // mi_render's pipeline: two device batch buffers and two streams, kept between calls
+  mi_trace_result* d_batch[2] = {nullptr, nullptr}; size_t batchCap[2] = {0, 0};
+  hipStream_t pipeStream[2] = {nullptr, nullptr};
   double traceTimeSecs = 0.0;
   float hdriRotationDegrees = 0.f;
   size_t maxNifBatch = 0;
@@ -102,11 +158,24 @@ struct mi_scene {
     if (d_slotColor) (void)hipFree(d_slotColor);
     if (d_slotTp) (void)hipFree(d_slotTp);
     if (d_segTotal) (void)hipFree(d_segTotal);
-    for (float* p : d_segPart) if (p) (void)hipFree(p);
+    for (LaunchSlot& l : slots) { if (l.d_workCounter) (void)hipFree(l.d_workCounter); if (l.d_segPart) (void)hipFree(l.d_segPart); }
+    for (int i = 0; i < 2; ++i) { if (d_batch[i]) (void)hipFree(d_batch[i]); if (pipeStream[i]) (void)hipStreamDestroy(pipeStream[i]); }
+    if (nifDone) (void)hipEventDestroy(nifDone);
     nif.release();
   }
   template <class T> T* keep(T* p) { if (p) allocations.push_back((void*)p); return p; }
+  // the launch slot of a stream (created on first use; a scene is thread-compatible, not thread-safe)
+  LaunchSlot& slotFor(hipStream_t stream);
 };
+
+LaunchSlot& mi_scene::slotFor(hipStream_t stream) {
+  for (LaunchSlot& l : slots) if (l.stream == stream) return l;
+  LaunchSlot l;
+  l.stream = stream;
+  HIP_CHECK(hipMalloc(&l.d_workCounter, sizeof(uint32_t)));
+  slots.push_back(l);
+  return slots.back();
+}
 
 namespace {
 
@@ -224,18 +293,15 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
   S.keep(S.d_counters);
   HIP_CHECK(hipMemset(S.d_counters, 0, 16 * sizeof(unsigned long long)));
   ds.counters = S.d_counters;
-  HIP_CHECK(hipMalloc(&S.d_workCounter, 2 * sizeof(uint32_t)));      // one per pipeline slot (mi_render batches)
-  S.keep(S.d_workCounter);
 }
 
 // Slots per pixel per launch in NIF renders (44 B each). A launch holds whole segments (ray_math.h segment_samples);
 // more samples per launch mean more (pixel, segment) atoms per lane and fewer launch tails: 128 by default, fewer
-// when n x samples x 44 B would pass 16 GiB (never less than one segment). MI_RAYLIB_NIF_SPL overrides (1..128,
+// when n x samples x 44 B would pass 16 GiB (never less than one segment). Option "nif_spl" overrides (1..128,
 // rounded up to whole segments).
 void ensureScratch(mi_scene& S, size_t n) {
   {
-    const char* e = getenv("MI_RAYLIB_NIF_SPL");
-    const uint32_t asked = e ? (uint32_t)atoi(e) : 0u;
+    const uint32_t asked = S.opt.nifSamplesPerLaunch;
     const uint32_t segLen = segment_samples(S.ds.samplesPerPixel);
     uint32_t v = (asked >= 1 && asked <= 128) ? asked : 128u;
     v = ((v + segLen - 1) / segLen) * segLen;
@@ -248,6 +314,7 @@ void ensureScratch(mi_scene& S, size_t n) {
     if (v != S.scratchSamples) { S.scratchSamples = v; S.scratchRays = 0; }     // slot buffers are sized for n x v
   }
   if (S.scratchRays >= n) return;
+  if (S.nifPending) { HIP_CHECK(hipDeviceSynchronize()); S.nifPending = false; }      // an earlier NIF render may still read the old buffers
   if (S.d_rng) (void)hipFree(S.d_rng);
   if (S.d_u) (void)hipFree(S.d_u);
   if (S.d_v) (void)hipFree(S.d_v);
@@ -267,101 +334,107 @@ void ensureScratch(mi_scene& S, size_t n) {
   S.scratchRays = n;
 }
 
-bool g_fullStats = false;
-WaveTune g_tune = {8, 16, 24, 48, 3};
-int g_kernelChoice = 1;           // 0 = nested-loop kernel, 1 = wavefront (global nodes), 2 = wavefront + LDS-staged nodes
-int g_wavesPerSimd = 5;          // MI_RAYLIB_WAVES=4: the 108-VGPR build of the default kernel (4 waves per SIMD)
-
 constexpr uint32_t kLdsBudgetBytes = 160 * 1024 - 1024 - 23 * 1024 * 4;     // 160 KiB per CU minus the static allocations (sin table, 23 cold-state words x 1024 threads)
 
+// Work indices are 32 bit and every wave takes them from the launch's counter in chunks of fetchChunk (64): a wave
+// that finds the counter past the end still adds its chunk, so the counter may overshoot the item count by
+// (waves of the grid) x fetchChunk. Launches stay below 2^32 minus that headroom (2048 workgroups x 16 waves x 64,
+// rounded up), so the counter never wraps.
+constexpr uint64_t kMaxWorkItems = 0xFFFFFFFFull - ((uint64_t)1 << 22);
+
 template <bool STATS>
-void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStream_t stream, int slot, const WaveExtras& ex = WaveExtras{}) {
-  uint32_t* workCounter = S.d_workCounter + slot;
+void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStream_t stream, const WaveExtras& ex = WaveExtras{}) {
+  LaunchSlot& slot = S.slotFor(stream);
+  uint32_t* workCounter = slot.d_workCounter;
   // Streams are walked in 8x8 pixel tiles of window-width rows (a whole window, a batch of it, or one rank's
   // 8-row bands are all sequences of full rows); the walk is only a work ORDER, any stream stays correct.
   const uint32_t w = (uint32_t)S.params.window_w;
-  static const bool noTiles = getenv("MI_RAYLIB_NO_TILES") != nullptr;
-  const uint32_t tileW = (!noTiles && w >= 8 && (w % 8) == 0 && cnt >= 8u * w) ? w : 0u;
+  const uint32_t tileW = (S.opt.tiles && w >= 8 && (w % 8) == 0 && cnt >= 8u * w) ? w : 0u;
   const bool plain = ex.slotColor == nullptr;      // NIF launches (slots) only exist for the default kernel
-  // Pixels with more than segment_samples(spp) samples are traced as (pixel, segment) work atoms (ray_math.h); the two
-  // pipeline slots of mi_render run on different streams, so each has its own partial-sum buffer.
+  // Pixels with more than segment_samples(spp) samples are traced as (pixel, segment) work atoms (ray_math.h); every
+  // stream has its own partial-sum buffer (LaunchSlot).
   const uint32_t segLen = segment_samples(S.ds.samplesPerPixel);
   const uint32_t segments = (S.ds.samplesPerPixel + segLen - 1) / segLen;
   const bool segmented = plain && segments > 1;
-  // One launch covers as many segments of every pixel as the partial-sum budget holds (8 GiB, MI_RAYLIB_SEG_BUDGET_KB
-  // overrides; the bench frame needs 0.4 GB); longer renders run as several launches whose combine passes continue
+  // One launch covers as many segments of every pixel as the partial-sum budget holds (8 GiB, option "seg_budget_kb";
+  // the bench frame needs 0.4 GB); longer renders run as several launches whose combine passes continue
   // the running sum in segment order, so the cut never shows in the result.
   uint32_t perLaunch = segments;
   if (segmented) {
-    const char* e = getenv("MI_RAYLIB_SEG_BUDGET_KB");
-    const size_t kb = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)8 * 1024 * 1024;
-    const size_t budgetFloats = std::max<size_t>(kb, 1) * (size_t)(1024 / sizeof(float));
+    const size_t budgetFloats = S.opt.segBudgetKb * (size_t)(1024 / sizeof(float));
     const uint64_t byBudget = std::max<uint64_t>(1, budgetFloats / ((uint64_t)3 * cnt));
-    const uint64_t byIndex = std::max<uint64_t>(1, 0xFFFFFFFFull / cnt);           // work indices are 32-bit
+    const uint64_t byIndex = std::max<uint64_t>(1, kMaxWorkItems / cnt);           // work indices are 32-bit
     perLaunch = (uint32_t)std::min<uint64_t>(segments, std::min(byBudget, byIndex));
     const size_t need = (size_t)3 * cnt * perLaunch;
-    if (S.segPartFloats[slot] < need) {
-      if (S.d_segPart[slot]) (void)hipFree(S.d_segPart[slot]);
-      S.d_segPart[slot] = nullptr; S.segPartFloats[slot] = 0;
-      HIP_CHECK(hipMalloc(&S.d_segPart[slot], need * sizeof(float)));
-      S.segPartFloats[slot] = need;
+    if (slot.segPartFloats < need) {
+      if (slot.d_segPart) { HIP_CHECK(hipStreamSynchronize(stream)); (void)hipFree(slot.d_segPart); }
+      slot.d_segPart = nullptr; slot.segPartFloats = 0;
+      HIP_CHECK(hipMalloc(&slot.d_segPart, need * sizeof(float)));
+      slot.segPartFloats = need;
     }
   }
   const uint32_t launches = segmented ? (segments + perLaunch - 1) / perLaunch : 1u;
   for (uint32_t l = 0; l < launches; ++l) {
     const uint32_t segBase = l * perLaunch;
     WaveExtras exs = ex;
-    if (segmented) { exs.segPart = S.d_segPart[slot]; exs.segments = std::min(perLaunch, segments - segBase); exs.segBase = segBase; }
+    if (segmented) { exs.segPart = slot.d_segPart; exs.segments = std::min(perLaunch, segments - segBase); exs.segBase = segBase; }
     HIP_CHECK(hipMemsetAsync(workCounter, 0, sizeof(uint32_t), stream));
     const uint64_t items = (uint64_t)cnt * ((segmented || !plain) ? exs.segments : 1u);     // work atoms of this launch
-    if (plain && g_kernelChoice == 2 && S.ds.numNodes > 0) {
+    if (items > kMaxWorkItems) throw ArgError("mi_render: too many work items for one launch (cut the stream with mi_scene_set_ray_batch)");
+    if (plain && S.opt.kernelChoice == 2 && S.ds.numNodes > 0) {
       // one 1024-thread workgroup per CU shares one LDS copy of the first nodes of the (preorder) array
       const uint32_t ldsNodes = std::min<uint32_t>(S.ds.numNodes, kLdsBudgetBytes / (uint32_t)sizeof(GNode));
       const size_t ldsBytes = (size_t)ldsNodes * sizeof(GNode);
       auto kern = path_trace_wavefront_kernel<STATS, true, 1024>;
-      static bool attrSet = false;
-      if (!attrSet) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes)); attrSet = true; }
+      if (!S.ldsAttrSet[STATS ? 1 : 0]) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
+        S.ldsAttrSet[STATS ? 1 : 0] = true;
+      }
       const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 1023) / 1024, 256);
-      hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, ldsNodes, g_tune, tileW, exs);
-    } else if (!STATS && g_wavesPerSimd == 5) {
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, ldsNodes, S.opt.tune, tileW, exs);
+    } else if (!STATS && S.opt.wavesPerSimd == 5) {
       // 96-VGPR build: 5 waves per SIMD (+4.6 % on the box scene; 6 waves = 80 VGPRs: -19 %, its spills land in LEAF/SHADE)
       const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 255) / 256, 256 * 8);
-      hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, 5>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, exs);
+      hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, 5>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
     } else {
       const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 255) / 256, 256 * 8);
-      hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, g_tune, tileW, exs);
+      hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
     }
-    if (segmented) hipLaunchKernelGGL(segment_combine_kernel, dim3((cnt + 255) / 256), dim3(256), 0, stream, d_rays, cnt, exs.segments, S.d_segPart[slot], segBase ? 1u : 0u);
+    if (segmented) hipLaunchKernelGGL(segment_combine_kernel, dim3((cnt + 255) / 256), dim3(256), 0, stream, d_rays, cnt, exs.segments, slot.d_segPart, segBase ? 1u : 0u);
   }
 }
 
-void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipStream_t stream, int slot = 0) {
+void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipStream_t stream) {
   if (n == 0) return;
   if (n > 0xFFFFFFFFull) throw ArgError("mi_render: more than 2^32-1 rays in one call");
   const uint32_t cnt = (uint32_t)n;
   const dim3 block(256), grid((cnt + 255) / 256);
   if (mode == MI_MODE_SHADOW_TRACE) {
     const f3 light = mk(18.f, 257.f, -1060.f);          // trace.cpp:247, src/IpuScene.cpp:447
-    if (g_fullStats) hipLaunchKernelGGL(shadow_trace_kernel<true>, grid, block, 0, stream, S.ds, d_rays, cnt, .05f, light);
+    if (S.opt.fullStats) hipLaunchKernelGGL(shadow_trace_kernel<true>, grid, block, 0, stream, S.ds, d_rays, cnt, .05f, light);
     else hipLaunchKernelGGL(shadow_trace_kernel<false>, grid, block, 0, stream, S.ds, d_rays, cnt, .05f, light);
   } else if (mode == MI_MODE_PATH_TRACE) {
-    if (!S.nif.loaded() && g_kernelChoice != 0 && S.ds.samplesPerPixel >= 1 && S.ds.maxPathLength >= 1) {
+    if (!S.nif.loaded() && S.opt.kernelChoice != 0 && S.ds.samplesPerPixel >= 1 && S.ds.maxPathLength >= 1) {
       // sample loop inside the kernel (src/IpuScene.cpp:441), phase-scheduled persistent form
-      if (g_fullStats) launchWavefront<true>(S, d_rays, cnt, stream, slot);
-      else launchWavefront<false>(S, d_rays, cnt, stream, slot);
+      if (S.opt.fullStats) launchWavefront<true>(S, d_rays, cnt, stream);
+      else launchWavefront<false>(S, d_rays, cnt, stream);
     } else if (!S.nif.loaded()) {
       // sample loop inside the kernel (src/IpuScene.cpp:441: vertexSampleCount = samplesPerPixel)
-      if (g_fullStats) hipLaunchKernelGGL(path_trace_kernel<true>, grid, block, 0, stream, S.ds, d_rays, cnt, 0u, S.ds.samplesPerPixel, (Rng*)nullptr);
+      if (S.opt.fullStats) hipLaunchKernelGGL(path_trace_kernel<true>, grid, block, 0, stream, S.ds, d_rays, cnt, 0u, S.ds.samplesPerPixel, (Rng*)nullptr);
       else hipLaunchKernelGGL(path_trace_kernel<false>, grid, block, 0, stream, S.ds, d_rays, cnt, 0u, S.ds.samplesPerPixel, (Rng*)nullptr);
     } else {
       // Repeat(spp){ trace 1 sample; uv pre-pass; NIF; env post-pass }  (src/IpuScene.cpp:571-583)
+      // NIF renders of one scene share its slot scratch: whatever streams they are enqueued on, each waits for the
+      // previous one (and a scratch re-allocation waits for the device)
+      if (!S.nifDone) HIP_CHECK(hipEventCreateWithFlags(&S.nifDone, hipEventDisableTiming));
+      if (S.nifPending) HIP_CHECK(hipStreamWaitEvent(stream, S.nifDone, 0));
       ensureScratch(S, n);
       const float radians = (S.hdriRotationDegrees / 360.f) * (float)(2.0 * M_PI);   // src/IpuScene.cpp:644
-      const bool wave = g_kernelChoice != 0 && S.ds.maxPathLength >= 1;
+      const bool wave = S.opt.kernelChoice != 0 && S.ds.maxPathLength >= 1;
       if (wave) {
         // persistent phase-scheduled kernel, several samples per launch; every path leaves a slot (WaveExtras), the
         // MLP runs on the compacted escaped slots, and a per-pixel pass adds everything in the reference's order
-        if ((uint64_t)cnt * S.scratchSamples > 0xFFFFFFFFull) throw ArgError("mi_render: ray batch too large for a NIF render (cut it with mi_scene_set_ray_batch)");
+        if ((uint64_t)cnt * S.scratchSamples > kMaxWorkItems) throw ArgError("mi_render: ray batch too large for a NIF render (cut it with mi_scene_set_ray_batch)");
         S.nif.ensureIndex((size_t)cnt * S.scratchSamples);
         const uint32_t segLen = segment_samples(S.ds.samplesPerPixel), segShift = segment_shift(S.ds.samplesPerPixel);
         for (uint32_t s0 = 0; s0 < S.ds.samplesPerPixel; s0 += S.scratchSamples) {
@@ -371,9 +444,9 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
           ex.sampleCount = sc; ex.segments = (sc + segLen - 1) / segLen; ex.segBase = s0 / segLen;     // (pixel, segment) atoms
           ex.u = S.d_u; ex.v = S.d_v; ex.slotColor = S.d_slotColor; ex.slotTp = S.d_slotTp;
           ex.index = S.nif.d_index; ex.count = S.nif.d_count; ex.azimuthRotation = radians;
-          if (g_fullStats) launchWavefront<true>(S, d_rays, cnt, stream, slot, ex);
-          else launchWavefront<false>(S, d_rays, cnt, stream, slot, ex);
-          nif_launch_mlp(S.nif, S.d_u, S.d_v, S.nif.d_index, S.nif.d_count, cnt * sc, S.d_bgr, nullptr, stream, true);
+          if (S.opt.fullStats) launchWavefront<true>(S, d_rays, cnt, stream, ex);
+          else launchWavefront<false>(S, d_rays, cnt, stream, ex);
+          nif_launch_mlp(S.nif, S.d_u, S.d_v, S.nif.d_index, S.nif.d_count, cnt * sc, S.d_bgr, nullptr, stream, true, S.opt.nifShape);
           hipLaunchKernelGGL(nif_accumulate_kernel, grid, block, 0, stream, d_rays, cnt, sc, segShift, ex.segBase, S.d_slotColor, S.d_slotTp, S.d_u, S.d_bgr);
         }
       } else {
@@ -381,12 +454,14 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
         for (uint32_t s = 0; s < S.ds.samplesPerPixel; ++s) {
           // a new segment: the finished ones move to the running total, rgb restarts from zero
           if (s != 0 && s % segLen == 0) hipLaunchKernelGGL(nif_segment_roll_kernel, grid, block, 0, stream, d_rays, S.d_segTotal, cnt, s / segLen, 0u);
-          if (g_fullStats) hipLaunchKernelGGL(path_trace_kernel<true>, grid, block, 0, stream, S.ds, d_rays, cnt, s, 1u, S.d_rng);
+          if (S.opt.fullStats) hipLaunchKernelGGL(path_trace_kernel<true>, grid, block, 0, stream, S.ds, d_rays, cnt, s, 1u, S.d_rng);
           else hipLaunchKernelGGL(path_trace_kernel<false>, grid, block, 0, stream, S.ds, d_rays, cnt, s, 1u, S.d_rng);
-          nif_env_pass(S.nif, d_rays, cnt, radians, S.d_u, S.d_v, S.d_bgr, S.maxNifBatch, stream);
+          nif_env_pass(S.nif, d_rays, cnt, radians, S.d_u, S.d_v, S.d_bgr, S.maxNifBatch, stream, S.opt.nifShape);
         }
         if (S.ds.samplesPerPixel > segLen) hipLaunchKernelGGL(nif_segment_roll_kernel, grid, block, 0, stream, d_rays, S.d_segTotal, cnt, 0u, 1u);
       }
+      HIP_CHECK(hipEventRecord(S.nifDone, stream));
+      S.nifPending = true;
     }
   } else {
     throw ArgError("mi_render: unknown render mode");
@@ -420,13 +495,7 @@ int mi_scene_create(const mi_scene_desc* desc, mi_scene** out) {
     S->params.geometry = nullptr; S->params.mesh_info = nullptr; S->params.mesh_tris = nullptr; S->params.mesh_verts = nullptr;
     S->params.mesh_normals = nullptr; S->params.mat_ids = nullptr; S->params.materials = nullptr; S->params.bvh_nodes = nullptr;
     S->params.spheres = nullptr; S->params.discs = nullptr;
-    if (const char* e = getenv("MI_RAYLIB_FULL_STATS")) g_fullStats = (e[0] == '1');
-    if (const char* e = getenv("MI_RAYLIB_TUNE")) {      // leafAt,shadeAt,genAt[,burst,keep8,dbl,maxExtra,leafThenNode,prio]
-      unsigned a, b, c, dd = 48, k8 = 3, db = 4, mx = 5, ln = 1, pr = 1;
-      if (sscanf(e, "%u,%u,%u,%u,%u,%u,%u,%u,%u", &a, &b, &c, &dd, &k8, &db, &mx, &ln, &pr) >= 3) g_tune = {a, b, c, dd, k8, db ? db : 65, mx, ln, pr};
-    }
-    if (const char* e = getenv("MI_RAYLIB_WAVES")) g_wavesPerSimd = (e[0] == '4') ? 4 : 5;
-    if (const char* e = getenv("MI_RAYLIB_KERNEL")) g_kernelChoice = (e[0] == '0') ? 0 : (e[0] == '2') ? 2 : 1;
+    S->opt.fromEnvironment();      // read once, into this scene (SceneOptions)
   });
   if (rc != MI_OK) { delete S; return rc; }
   *out = S;
@@ -475,24 +544,35 @@ int mi_render(mi_scene* scene, int mode, mi_trace_result* rays, size_t n, mi_ray
     const size_t batch = (scene->rayBatch && scene->rayBatch < n) ? scene->rayBatch : n;
     const size_t numBatches = (n + batch - 1) / batch;
     const int slots = (numBatches > 1 && !scene->nif.loaded()) ? 2 : 1;
-    mi_trace_result* d[2] = {nullptr, nullptr};
-    hipStream_t st[2] = {nullptr, nullptr};
+    // The two device batch buffers and the two streams belong to the scene and are kept between calls (a preview
+    // loop of short renders would otherwise pay an allocation, two stream creations and their tear-down per call).
+    for (int i = 0; i < slots; ++i) {
+      if (scene->batchCap[i] < batch) {
+        if (scene->d_batch[i]) { HIP_CHECK(hipDeviceSynchronize()); (void)hipFree(scene->d_batch[i]); }
+        scene->d_batch[i] = nullptr; scene->batchCap[i] = 0;
+        HIP_CHECK(hipMalloc(&scene->d_batch[i], batch * sizeof(mi_trace_result)));
+        scene->batchCap[i] = batch;
+      }
+      if (!scene->pipeStream[i]) HIP_CHECK(hipStreamCreateWithFlags(&scene->pipeStream[i], hipStreamNonBlocking));
+    }
+    mi_trace_result* const* d = scene->d_batch;
+    hipStream_t const* st = scene->pipeStream;
     // The caller's stream is page-locked for the duration of the call, so the copies are real DMA transfers that
     // overlap the kernels of the other slot (pageable copies go through a staging buffer and serialise). Memory that
-    // cannot be registered (or MI_RAYLIB_PIN=0) just takes the pageable route.
+    // cannot be registered (or option "pin" = 0) just takes the pageable route; memory the caller has already
+    // page-locked (hipHostMalloc / hipHostRegister / torch pin_memory) is used as it is.
     bool pinned = false;
-    {
-      const char* e = getenv("MI_RAYLIB_PIN");
-      if (!(e && e[0] == '0') && n * sizeof(mi_trace_result) >= (size_t)1 << 20)
+    if (scene->opt.pin && n * sizeof(mi_trace_result) >= (size_t)1 << 20) {
+      hipPointerAttribute_t attr{};
+      const bool known = hipPointerGetAttributes(&attr, rays) == hipSuccess && attr.type == hipMemoryTypeHost;
+      if (!known) {
+        (void)hipGetLastError();
         pinned = hipHostRegister(rays, n * sizeof(mi_trace_result), hipHostRegisterDefault) == hipSuccess;
-      if (!pinned) (void)hipGetLastError();
+        if (!pinned) (void)hipGetLastError();
+      }
     }
-    auto cleanup = [&] {
-      for (int i = 0; i < 2; ++i) { if (d[i]) (void)hipFree(d[i]); if (st[i]) (void)hipStreamDestroy(st[i]); }
-      if (pinned) (void)hipHostUnregister(rays);
-    };
+    auto cleanup = [&] { if (pinned) (void)hipHostUnregister(rays); };
     try {
-      for (int i = 0; i < slots; ++i) { HIP_CHECK(hipMalloc(&d[i], batch * sizeof(mi_trace_result))); HIP_CHECK(hipStreamCreate(&st[i])); }
       const auto t0 = std::chrono::steady_clock::now();
       auto finish = [&](size_t b) {
         HIP_CHECK(hipStreamSynchronize(st[b % slots]));
@@ -504,7 +584,7 @@ int mi_render(mi_scene* scene, int mode, mi_trace_result* rays, size_t n, mi_ray
         if (b >= (size_t)slots) finish(b - slots);
         const size_t first = b * batch, cnt = std::min(batch, n - first);
         HIP_CHECK(hipMemcpyAsync(d[i], rays + first, cnt * sizeof(mi_trace_result), hipMemcpyHostToDevice, st[i]));
-        launchRender(*scene, mode, d[i], cnt, st[i], i);
+        launchRender(*scene, mode, d[i], cnt, st[i]);
         HIP_CHECK(hipMemcpyAsync(rays + first, d[i], cnt * sizeof(mi_trace_result), hipMemcpyDeviceToHost, st[i]));
       }
       for (size_t b = (numBatches > (size_t)slots ? numBatches - slots : 0); b < numBatches; ++b) finish(b);
@@ -512,6 +592,12 @@ int mi_render(mi_scene* scene, int mode, mi_trace_result* rays, size_t n, mi_ray
     } catch (...) { (void)hipDeviceSynchronize(); cleanup(); throw; }
     cleanup();
   });
+}
+
+int mi_scene_set_option(mi_scene* scene, const char* key, const char* value) {
+  if (!scene || !key || !value) { g_err = "mi_scene_set_option: null argument"; return MI_ERR_INVALID_ARG; }
+  if (!scene->opt.set(key, value)) { g_err = std::string("mi_scene_set_option: unknown option or bad value: ") + key + "=" + value; return MI_ERR_INVALID_ARG; }
+  return MI_OK;
 }
 
 double mi_trace_time_secs(const mi_scene* scene) { return scene ? scene->traceTimeSecs : 0.0; }
@@ -581,7 +667,7 @@ int mi_nif_infer_device(mi_scene* scene, const float* d_u, const float* d_v, flo
   if (!scene->nif.loaded()) { g_err = "mi_nif_infer_device: no NIF model loaded"; return MI_ERR_NO_NIF; }
   return guarded([&] {
     HIP_CHECK(hipSetDevice(scene->device));
-    nif_infer(scene->nif, d_u, d_v, d_bgr, n, scene->maxNifBatch, (hipStream_t)hip_stream);
+    nif_infer(scene->nif, d_u, d_v, d_bgr, n, scene->maxNifBatch, (hipStream_t)hip_stream, scene->opt.nifShape);
     HIP_CHECK(hipGetLastError());
   });
 }

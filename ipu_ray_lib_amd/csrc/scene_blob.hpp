@@ -12,8 +12,14 @@
 //     (arrays, in this order), then maxLeafDepth u32, imageWidth f32, imageHeight f32, fovRadians f32,
 //     antiAliasScale f32, maxPathLength u32, rouletteStartDepth u32, samplesPerPixel u32.
 //     rngSeed, the crop window and pathTrace are NOT in the blob (they travel as separate tensors).
-// Element alignments are those of the reference structs: GeomRef 2, MeshInfo 4, Triangle 2, Vec3fa 4,
-// u32 4, Material 4, CompactBVH2Node 4 (24 bytes, stays compact for BaseAlign >= 4).
+// Element alignments are alignof() of the reference structs (Serialiser::write(const T*, n) pads to alignof(T),
+// Serialiser.hpp:33-60; deserialiseArrayRef<T> skips the same, deserialisation.hpp:31-38):
+//   GeomRef 2 (Scene.hpp:29-34: u16 + 2 x u8)        MeshInfo 4 (Mesh.hpp:15-20: 4 x u32)
+//   Triangle 2 (Primitives.hpp:21-25: packed, aligned(alignof(u16)))
+//   Vec3fa 4 (embree_utils/geometry.hpp:25-27: VEC3_ALIGN 4)      u32 4
+//   Material 4 (Material.hpp:8-35: Vec3fa, float, enum, bool)
+//   CompactBVH2Node 8 (CompactBVH2Node.hpp:52-53: __attribute__((aligned(8))), 24 bytes) - so the node array
+//   is preceded by 4 pad bytes whenever the byte after its u32 count falls on (BaseAlign + offset) % 8 == 4.
 // Parity note: the reference's Serialiser cannot be compiled here (boost::alignment + Eigen::half are
 // absent), so this format is pinned by the properties its unit tests check (tests/test.cpp:38-237),
 // restated in tests/test_scene_blob.py, and by an independent numpy packer in that test.
@@ -27,6 +33,8 @@
 #include "../../include/mi_raylib.h"
 
 namespace mi::blob {
+
+constexpr uint32_t kNodeAlign = 8;     // alignof(CompactBVH2Node), CompactBVH2Node.hpp:52-53
 
 inline uint32_t padding(uint32_t baseAlign, size_t offset, uint32_t align) {
   const size_t rem = (baseAlign + offset) % align;
@@ -93,7 +101,7 @@ inline void serialiseScene(Writer& w, const mi_scene_desc& d) {
   w.writeArray(d.mesh_normals, d.num_normals, sizeof(mi_vec3), 4);
   w.writeArray(d.mat_ids, d.num_mat_ids, 4, 4);
   w.writeArray(d.materials, d.num_materials, sizeof(mi_material), 4);
-  w.writeArray(d.bvh_nodes, d.num_nodes, sizeof(mi_bvh_node), 4);
+  w.writeArray(d.bvh_nodes, d.num_nodes, sizeof(mi_bvh_node), kNodeAlign);
   w.write<uint32_t>(d.max_leaf_depth);
   w.write<float>(d.image_width);
   w.write<float>(d.image_height);
@@ -114,7 +122,7 @@ inline size_t deserialiseScene(const uint8_t* bytes, size_t n, mi_scene_desc& d,
   d.mesh_normals = (const mi_vec3*)r.arrayRef(d.num_normals, sizeof(mi_vec3), 4);
   d.mat_ids = (const uint32_t*)r.arrayRef(d.num_mat_ids, 4, 4);
   d.materials = (const mi_material*)r.arrayRef(d.num_materials, sizeof(mi_material), 4);
-  d.bvh_nodes = (const mi_bvh_node*)r.arrayRef(d.num_nodes, sizeof(mi_bvh_node), 4);
+  d.bvh_nodes = (const mi_bvh_node*)r.arrayRef(d.num_nodes, sizeof(mi_bvh_node), kNodeAlign);
   r.read<uint32_t>(d.max_leaf_depth);
   r.read<float>(d.image_width);
   r.read<float>(d.image_height);

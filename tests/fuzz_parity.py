@@ -2,7 +2,8 @@
 
     python tests/fuzz_parity.py [seconds=240] [seed=1] [size_scale=1] [nif]
 
-Not collected by pytest (run it on a GPU box; it is test infrastructure like the rest of tests/). Every case draws
+A fixed slice of both campaigns is collected by pytest (tests/test_gpu_parity.py::test_fuzz_campaign_slice, -m gpu);
+the script form runs for a time budget. Every case draws
 a scene (built-in scenes, or a random triangle soup with nasty triangles: zero-area, needle, axis-aligned and
 duplicated/coplanar ones, with or without vertex normals, plus spheres and discs), render parameters (image size
 incl. ragged widths, crop window, 1..900 samples so that both segment lengths and their boundaries are crossed, seed, jitter, path length,
@@ -102,12 +103,16 @@ def nif_weights(rng, hidden, embed, layers):
     return ks, bs, [1] * (len(dims) - 1) + [0]
 
 
-def nif_campaign(budget, seed):
+class Mismatch(AssertionError):
+    pass
+
+
+def nif_campaign(budget, seed, max_cases=None):
     rng = np.random.default_rng(seed)
     builtins = {n: irl.HostScene.builtin(n) for n in ("box-simple", "box", "spheres", "monkey")}
     t_end = time.time() + budget
     case = rays_total = 0
-    while time.time() < t_end:
+    while time.time() < t_end and (max_cases is None or case < max_cases):
         case += 1
         name = str(rng.choice(list(builtins))); s = builtins[name]; d = s.desc
         w = int(rng.integers(1, 12)) * 8 + int(rng.integers(0, 2)) * int(rng.integers(1, 8))
@@ -127,12 +132,9 @@ def nif_campaign(budget, seed):
                 f"roulette={d.roulette_start_depth} mlp={layers}x{hidden} spl={spl or 'default'} rot={rot:.2f}")
 
         def render(kernel):
-            os.environ["MI_RAYLIB_KERNEL"] = kernel
+            dev = irl.IpuScene(d).set_option("kernel", kernel)
             if spl:
-                os.environ["MI_RAYLIB_NIF_SPL"] = spl
-            else:
-                os.environ.pop("MI_RAYLIB_NIF_SPL", None)
-            dev = irl.IpuScene(d)
+                dev.set_option("nif_spl", spl)
             dev.setNif(ks, bs, relu, 12, 3.43, np.array([-2.35, -2.26, -1.96], np.float32), True)
             dev.setHdriRotation(rot)
             rays = s.init_ray_stream()
@@ -144,27 +146,23 @@ def nif_campaign(budget, seed):
         bad = differing(batched, literal)
         if bad.size:
             i = int(bad[0])
-            print(f"MISMATCH {desc}\n {bad.size}/{batched.size} TraceResults differ; first at {i}:\n batched {batched[i]}\n literal {literal[i]}", flush=True)
-            sys.exit(1)
+            raise Mismatch(f"MISMATCH {desc}\n {bad.size}/{batched.size} TraceResults differ; first at {i}:\n batched {batched[i]}\n literal {literal[i]}")
         rays_total += batched.size
         if case % 20 == 0:
             print(f"{case} NIF cases, {rays_total} TraceResults identical; last: {desc}", flush=True)
     print(f"OK: {case} NIF cases, {rays_total} TraceResults, batched form bit-identical to the literal per-sample loop (seed {seed}, {budget:.0f} s)")
+    return case, rays_total
 
 
-def main():
-    if len(sys.argv) > 4 and sys.argv[4] == "nif":
-        return nif_campaign(float(sys.argv[1]), int(sys.argv[2]))
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1            # image edges up to 160 x scale pixels
+def campaign(budget=240.0, seed=1, scale=1, max_cases=None):
+    """image edges up to 160 x scale pixels"""
     rng = np.random.default_rng(seed)
     threads = os.cpu_count() or 8
     builtins = {n: irl.HostScene.builtin(n) for n in ("box-simple", "box", "spheres")}
     t_end = time.time() + budget
     case = 0
     rays_total = 0
-    while time.time() < t_end:
+    while time.time() < t_end and (max_cases is None or case < max_cases):
         case += 1
         if rng.random() < 0.55:
             s, what = soup(rng)
@@ -190,11 +188,10 @@ def main():
         d.path_trace = 1 if mode == irl.MODE_PATH_TRACE else 0
         kernel = str(rng.choice(["0", "1", "1", "1", "2"]))
         waves = str(rng.choice(["4", "5"]))
-        os.environ["MI_RAYLIB_KERNEL"] = kernel; os.environ["MI_RAYLIB_WAVES"] = waves
         batch = int(rng.integers(1, 4000)) if rng.random() < 0.25 else 0
         desc = (f"case {case} (seed {seed}): {what} {w}x{h} crop={crop} spp={spp} rngseed={d.rng_seed} aa={d.anti_alias_scale} "
                 f"len={d.max_path_length} roulette={d.roulette_start_depth} mode={mode} kernel={kernel} waves={waves} batch={batch}")
-        dev = irl.IpuScene(d)
+        dev = irl.IpuScene(d).set_option("kernel", kernel).set_option("waves", waves)
         got = s.init_ray_stream()
         if rng.random() < 0.3:
             for k in "xyz":
@@ -210,12 +207,24 @@ def main():
         bad = differing(got, want)
         if bad.size:
             i = int(bad[0])
-            print(f"MISMATCH {desc}\n {bad.size}/{got.size} TraceResults differ; first at {i}:\n got  {got[i]}\n want {want[i]}", flush=True)
-            sys.exit(1)
+            raise Mismatch(f"MISMATCH {desc}\n {bad.size}/{got.size} TraceResults differ; first at {i}:\n got  {got[i]}\n want {want[i]}")
         rays_total += got.size
         if case % 20 == 0:
             print(f"{case} cases, {rays_total} TraceResults identical; last: {desc}", flush=True)
     print(f"OK: {case} cases, {rays_total} TraceResults, all bit-identical to the oracle (seed {seed}, {budget:.0f} s)")
+    return case, rays_total
+
+
+def main():
+    try:
+        if len(sys.argv) > 4 and sys.argv[4] == "nif":
+            nif_campaign(float(sys.argv[1]), int(sys.argv[2]))
+        else:
+            campaign(float(sys.argv[1]) if len(sys.argv) > 1 else 240.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
+                     int(sys.argv[3]) if len(sys.argv) > 3 else 1)
+    except Mismatch as e:
+        print(e, flush=True)
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -55,14 +55,13 @@ def test_shadow_trace_512_bit_exact(scenes, name):
     dev.close()
 
 
-def test_traversal_visits_exactly_the_reference_nodes(scenes, monkeypatch):
+def test_traversal_visits_exactly_the_reference_nodes(scenes):
     """Instrumented kernel variant: the number of BVH nodes visited and of primitive tests must equal the
     oracle's stack traversal — i.e. the stackless walk reproduces the reference's visit order."""
-    monkeypatch.setenv("MI_RAYLIB_FULL_STATS", "1")
     s = scenes["box"]
     s.desc.set_image(256, 256)
     s.desc.samples_per_pixel = 3
-    dev = irl.IpuScene(s.desc)
+    dev = irl.IpuScene(s.desc).set_option("full_stats", 1)
     got = s.init_ray_stream(); want = got.copy()
     dev.run(got, irl.MODE_SHADOW_TRACE)
     st = ol.shadow_trace(s.desc, want, 16)
@@ -76,8 +75,6 @@ def test_traversal_visits_exactly_the_reference_nodes(scenes, monkeypatch):
     assert (c["casts"], c["nodes_visited"], c["leaf_tests"], c["paths"]) == (st.casts, st.nodesVisited, st.leafTests, st.paths)
     assert_streams_identical(got, want, "instrumented path trace")
     dev.close()
-    monkeypatch.setenv("MI_RAYLIB_FULL_STATS", "0")
-    irl.IpuScene(s.desc).close()   # restore the default (un-instrumented) kernels for later tests
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -85,17 +82,15 @@ def test_traversal_visits_exactly_the_reference_nodes(scenes, monkeypatch):
 # ------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("kernel", ["0", "1", "1w4", "2"])
 @pytest.mark.parametrize("name,size,spp", [("box-simple", 128, 32), ("box", 160, 24), ("spheres", 128, 32)])
-def test_path_trace_bit_exact(scenes, name, size, spp, kernel, monkeypatch):
+def test_path_trace_bit_exact(scenes, name, size, spp, kernel):
     """kernel 0 = nested-loop kernel, 1 = phase-scheduled persistent kernel, 2 = the same with the BVH
     prefix staged in LDS; 1 is built for 5 waves per SIMD (default) and for 4 ("1w4"). All of them must reproduce
     the oracle bit for bit."""
-    monkeypatch.setenv("MI_RAYLIB_KERNEL", kernel[0])
-    monkeypatch.setenv("MI_RAYLIB_WAVES", "4" if kernel.endswith("w4") else "5")
     s = scenes[name]
     s.desc.set_image(size, size)
     s.desc.path_trace = 1
     s.desc.samples_per_pixel = spp
-    dev = irl.IpuScene(s.desc)
+    dev = irl.IpuScene(s.desc).set_option("kernel", kernel[0]).set_option("waves", 4 if kernel.endswith("w4") else 5)
     got = s.init_ray_stream(); want = got.copy()
     dev.run(got, irl.MODE_PATH_TRACE)
     st = ol.path_trace_pixel_rng(s.desc, want, 16)
@@ -105,9 +100,6 @@ def test_path_trace_bit_exact(scenes, name, size, spp, kernel, monkeypatch):
     assert np.isfinite(rgb).all()
     assert rgb.sum() > 0 or name == "spheres"        # 'spheres' has no emitter: it is lit by the NIF environment only
     dev.close()
-    monkeypatch.setenv("MI_RAYLIB_KERNEL", "1")
-    monkeypatch.setenv("MI_RAYLIB_WAVES", "5")
-    irl.IpuScene(s.desc).close()                      # back to the default kernel for the other tests
 
 
 @pytest.mark.parametrize("maxlen,roulette,aa,seed", [(1, 3, 0.25, 1442), (3, 0, 0.0, 7), (10, 1, 1.5, 2**40 + 3), (0, 3, 0.25, 1)])
@@ -391,20 +383,19 @@ def _nif_weights(rng, hidden=320, embed=12, layers=6):
 
 
 @pytest.mark.parametrize("shape", ["w6", "t4", "t6"])
-def test_nif_mlp_against_oracle(scenes, shape, monkeypatch):
+def test_nif_mlp_against_oracle(scenes, shape):
     """(every workgroup shape of the kernel: w6 is the default, the others are selectable)
     MFMA MLP vs the oracle's fp16-rounded-inputs / fp32-accumulate restatement. Tolerance: the decoded
     (exp'd) radiance must agree to 2% relative + 1e-3 absolute for 99.9% of samples and 10% for all — fp32
     accumulation ORDER differs (MFMA 32-wide k blocks vs sequential), activations are re-rounded to binary16
     at every layer so a 1-ulp fp32 difference can flip a binary16 rounding, and exp amplifies by |y*max|."""
     import torch
-    monkeypatch.setenv("MI_RAYLIB_NIF_SHAPE", shape)
     rng = np.random.default_rng(5)
     ks, bs, relu = _nif_weights(rng)
     mean = np.array([-2.3514461517333984, -2.2660605907440186, -1.9648972749710083], np.float32) - np.float32(1e-8)
     maxv = 3.4299468994140625
     s = scenes["spheres"]
-    dev = irl.IpuScene(s.desc)
+    dev = irl.IpuScene(s.desc).set_option("nif_shape", shape)
     dev.setNif(ks, bs, relu, 12, maxv, mean, True)
     n = 10000 + 37                                           # ragged: not a multiple of 64
     u = rng.random(n).astype(np.float32); v = rng.random(n).astype(np.float32)
@@ -553,7 +544,7 @@ def test_rank_streams_render_like_the_whole_frame(scenes, world):
 
 
 @pytest.mark.parametrize("spl,spp", [("32", 53), ("16", 53), ("64", 53), ("1", 19), ("64", 700), ("128", 700)])
-def test_nif_render_sample_batching_is_order_exact(scenes, spl, spp, monkeypatch):
+def test_nif_render_sample_batching_is_order_exact(scenes, spl, spp):
     """NIF renders trace several samples per launch - whole segments, as (pixel, segment) work atoms - and replay the
     reference's per-sample order afterwards (rgb += radiance, then rgb += throughput * env, per segment; segments
     added in order). Whatever the samples-per-launch setting (rounded up to whole segments: 4 samples at 19 and 53 spp,
@@ -568,9 +559,7 @@ def test_nif_render_sample_batching_is_order_exact(scenes, spl, spp, monkeypatch
     d.samples_per_pixel = spp; d.path_trace = 1
 
     def render(kernel):
-        monkeypatch.setenv("MI_RAYLIB_KERNEL", kernel)
-        monkeypatch.setenv("MI_RAYLIB_NIF_SPL", spl)
-        dev = irl.IpuScene(d)
+        dev = irl.IpuScene(d).set_option("kernel", kernel).set_option("nif_spl", spl)
         dev.setNif(ks, bs, relu, 12, 3.43, mean, True)
         dev.setHdriRotation(12.5)
         rays = s.init_ray_stream()
@@ -580,8 +569,6 @@ def test_nif_render_sample_batching_is_order_exact(scenes, spl, spp, monkeypatch
 
     literal = render("0")
     batched = render("1")
-    monkeypatch.setenv("MI_RAYLIB_KERNEL", "1"); monkeypatch.setenv("MI_RAYLIB_NIF_SPL", "32")
-    irl.IpuScene(d).close()                                  # restore the defaults for later tests
     assert_streams_identical(batched, literal, f"NIF render, {spp} spp, {spl} samples per launch")
     assert np.stack([batched["rgb"][k] for k in "xyz"], 1).max() > 0
 
@@ -618,17 +605,16 @@ def test_randomised_render_parameters_against_oracle(scenes):
 
 
 @pytest.mark.parametrize("kernel,spp", [("0", 300), ("1", 300), ("2", 300), ("0", 700), ("1", 700), ("2", 700)])
-def test_segmented_pixels_bit_exact(scenes, kernel, spp, monkeypatch):
+def test_segmented_pixels_bit_exact(scenes, kernel, spp):
     """More samples per pixel than one segment holds: the pixel is traced as segments (about sixteen per pixel, 4 to 64
     samples long), each with its own RNG stream and partial rgb sum, added in segment order.
     300 spp = nine full 32-sample segments + one of 12; 700 spp = ten full 64-sample segments + one of 60; the incoming
     rgb is non-zero (segment 0 accumulates onto it). Every kernel variant - the persistent kernel traces (pixel,
     segment) work atoms, the nested-loop kernel loops over the segments in one thread - must reproduce the oracle bit
     for bit; so must a batched render (both pipeline slots, each with its own partial-sum buffer)."""
-    monkeypatch.setenv("MI_RAYLIB_KERNEL", kernel)
     s = scenes["box"]; d = s.desc
     d.set_image(72, 40); d.samples_per_pixel = spp; d.path_trace = 1
-    dev = irl.IpuScene(d)
+    dev = irl.IpuScene(d).set_option("kernel", kernel)
     got = s.init_ray_stream()
     rng = np.random.default_rng(3)
     for k in "xyz":
@@ -645,11 +631,175 @@ def test_segmented_pixels_bit_exact(scenes, kernel, spp, monkeypatch):
     # each; one segment of this frame is 34.5 KB) whose combine passes continue the running sum
     dev.setRayBatch(0)
     for kb in ("64", "100"):
-        monkeypatch.setenv("MI_RAYLIB_SEG_BUDGET_KB", kb)
+        dev.set_option("seg_budget_kb", kb)
         cut = fresh.copy()
         dev.run(cut, irl.MODE_PATH_TRACE)
         assert_streams_identical(cut, want, f"segmented pixels, {kb} KB of partial sums, kernel {kernel}")
-    monkeypatch.delenv("MI_RAYLIB_SEG_BUDGET_KB")
     dev.close()
-    monkeypatch.setenv("MI_RAYLIB_KERNEL", "1")
-    irl.IpuScene(d).close()
+
+
+# ------------------------------------------------------------------------------------------------------
+# BASELINE configs at their REAL size: the full frame on the GPU, a 1-in-N pixel subsample through the oracle at the
+# full sample count (every pixel owns its RNG streams, so any subset of pixels is exact on its own)
+# ------------------------------------------------------------------------------------------------------
+def _subsample_check(s, dev, stride, what, threads=16):
+    got = s.init_ray_stream()
+    dev.run(got, irl.MODE_PATH_TRACE)
+    sub = s.init_ray_stream()[::stride].copy()
+    st = ol.path_trace_pixel_rng(s.desc, sub, threads)
+    assert_streams_identical(got[::stride].copy(), sub, what)
+    return got, st
+
+
+def test_config2_headline_frame_1440_x_1000spp_against_oracle(scenes):
+    """BASELINE config 2, the frame bench.py times: box scene, 1440x1440 x 1000 spp (sixteen segments per pixel, the
+    last of 40 samples; 0.4 GB of partial sums; segment_combine_kernel). Every 509th pixel (4 074 pixels, all 84
+    bytes) against the oracle at the full 1000 spp, plus whole-frame sanity."""
+    s = scenes["box"]; d = s.desc
+    d.set_image(1440, 1440); d.samples_per_pixel = 1000; d.path_trace = 1
+    dev = irl.IpuScene(d)
+    got, st = _subsample_check(s, dev, 509, "config 2: 1440^2 x 1000 spp, 1-in-509 subsample")
+    c = dev.counters()
+    assert c["paths"] == 1440 * 1440 * 1000
+    assert abs(c["casts"] / c["paths"] - st.casts / st.paths) < 0.02        # the subsample's casts per path speak for the frame
+    rgb = np.stack([got["rgb"][k] for k in "xyz"], 1) / 1000.0
+    assert np.isfinite(rgb).all() and 0.05 < rgb.mean() < 5.0
+    dev.close()
+    d.set_image(96, 64); d.samples_per_pixel = 5
+
+
+def test_config3_collada_1440_x_4000spp_against_oracle():
+    """BASELINE config 3 at its real size: assets/test_scene.dae --load-normals, 1440x1440 x 4000 spp (63 segments per
+    pixel). Every 1031st pixel (2 012 pixels) against the oracle at 4000 spp."""
+    s = irl.HostScene.import_file(irl.REPO_ROOT / "assets" / "test_scene.dae", load_normals=True)
+    d = s.desc
+    d.set_image(1440, 1440); d.samples_per_pixel = 4000; d.path_trace = 1
+    dev = irl.IpuScene(d)
+    got, st = _subsample_check(s, dev, 1031, "config 3: test_scene.dae 1440^2 x 4000 spp, 1-in-1031 subsample")
+    assert dev.counters()["paths"] == 1440 * 1440 * 4000
+    rgb = np.stack([got["rgb"][k] for k in "xyz"], 1) / 4000.0
+    assert np.isfinite(rgb).all() and rgb.mean() > 0
+    dev.close()
+
+
+def test_config5_monkey_nif_1440_x_256spp_against_oracle():
+    """BASELINE config 5's scene at 1440x1440 x 256 spp on one GPU (two 128-sample launches of slots, MLP over the
+    compacted escaped rays, accumulate pass): every 2053rd pixel (1 011 pixels) against the oracle's NIF render.
+    Hit records bit exact; rgb sums within the MLP tolerance stated in test_nif_mlp_against_oracle (2 % relative
+    on the decoded radiance; a pixel's sum averages 256 samples, so 1 % + a small absolute term for 99.5 % of the
+    pixels, 10 % for all)."""
+    rng = np.random.default_rng(8)
+    ks, bs, relu = _nif_weights(rng)
+    mean = np.array([-2.3514461517333984, -2.2660605907440186, -1.9648972749710083], np.float32) - np.float32(1e-8)
+    s = irl.HostScene.builtin("monkey"); d = s.desc
+    d.set_image(1440, 1440); d.samples_per_pixel = 256; d.path_trace = 1
+    dev = irl.IpuScene(d)
+    dev.setNif(ks, bs, relu, 12, 3.4299468994140625, mean, True)
+    got = s.init_ray_stream()
+    dev.run(got, irl.MODE_PATH_TRACE)
+    want = s.init_ray_stream()[::2053].copy()
+    nif, keep = ol.make_nif(ks, bs, relu, 12, 3.4299468994140625, mean, True, half_features=True, half_weights_acts=True)
+    st = ol.Stats()
+    ol.lib().o_path_trace_nif_pixel_rng(C.byref(d), C.byref(nif), 0.0, want.ctypes.data, want.size, 16, C.byref(st))
+    sub = got[::2053].copy()
+    assert rows_differing(np.ascontiguousarray(sub["h"]), np.ascontiguousarray(want["h"])).size == 0, "config 5: hit records must be bit exact"
+    g = np.stack([sub["rgb"][k] for k in "xyz"], 1); w = np.stack([want["rgb"][k] for k in "xyz"], 1)
+    assert w.max() > 0 and (sub["h"]["flags"] & irl.FLAG_ESCAPED).mean() > 0.2
+    err = np.abs(g - w) / (np.abs(w) + 0.05 * 256)
+    assert np.quantile(err, 0.995) < 0.01 and err.max() < 0.1, (np.quantile(err, 0.995), err.max())
+    assert dev.counters()["paths"] == 1440 * 1440 * 256
+    dev.close()
+
+
+def test_gpu_image_against_the_literal_renderCPU_statistically(scenes):
+    """Tier 2 on the GPU: the image the HIP path renders (per-pixel streams) against the oracle's literal restatement
+    of renderCPU (trace.cpp:190-268: ONE shared generator consumed sequentially, libstdc++ normal_distribution
+    jitter) at 64 and 256 spp. Different random numbers, same estimator - the reference's own acceptance method
+    (notebook cells 18-19): channel means agree within the Monte-Carlo error, the cross-scheme MSE equals the MSE
+    between two GPU renders with different seeds, and falls like 1/spp."""
+    s = scenes["box"]; d = s.desc
+    d.set_image(120, 120); d.path_trace = 1
+    mse = {}
+    for spp in (64, 256):
+        d.samples_per_pixel = spp
+        imgs = []
+        for seed in (1442, 99):
+            d.rng_seed = seed
+            dev = irl.IpuScene(d)
+            r = s.init_ray_stream(); dev.run(r, irl.MODE_PATH_TRACE); dev.close()
+            imgs.append(np.stack([r["rgb"][k] for k in "xyz"], 1) / spp)
+        d.rng_seed = 1442
+        ref = s.init_ray_stream(); ol.path_trace_shared_rng(d, ref)
+        ref = np.stack([ref["rgb"][k] for k in "xyz"], 1) / spp
+        # channel means: one 120x120 render's mean has a relative sigma of about 1.2 % at 64 spp and 0.6 % at 256 spp
+        # (sigma of a 40x40 render, tests/test_oracle_tiers.py, scaled by sqrt(pixels x spp)); 4 sigma of a difference
+        tol = {64: 0.07, 256: 0.035}[spp]
+        assert np.allclose(imgs[0].mean(0), ref.mean(0), rtol=tol), (spp, imgs[0].mean(0), ref.mean(0))
+        cross = np.mean((imgs[0] - ref) ** 2); same = np.mean((imgs[0] - imgs[1]) ** 2)
+        assert 0.5 < cross / same < 2.0, (spp, cross, same)
+        mse[spp] = cross
+    assert 2.0 < mse[64] / mse[256] < 8.0, mse
+    d.set_image(96, 64); d.samples_per_pixel = 5; d.rng_seed = 1442
+
+
+def test_fuzz_campaign_slice():
+    """A fixed slice of tests/fuzz_parity.py (the differential campaign whose long runs are logged under profiles/):
+    120 random scene / parameter / kernel-variant cases against the oracle and 30 NIF batching cases, every byte of
+    every TraceResult."""
+    import fuzz_parity
+    cases, rays = fuzz_parity.campaign(budget=600.0, seed=20260101, scale=1, max_cases=120)
+    assert cases == 120 and rays > 0
+    cases, rays = fuzz_parity.nif_campaign(600.0, 20260102, max_cases=30)
+    assert cases == 30 and rays > 0
+
+
+# ------------------------------------------------------------------------------------------------------
+# per-scene state (mi_scene_set_option): nothing one scene selects may change what another scene launches
+# ------------------------------------------------------------------------------------------------------
+def test_scene_options_are_per_scene(scenes, monkeypatch):
+    s = scenes["box"]; d = s.desc
+    d.set_image(64, 48); d.samples_per_pixel = 6; d.path_trace = 1
+    want = s.init_ray_stream(); st = ol.path_trace_pixel_rng(d, want, 16)
+    plain = irl.IpuScene(d)
+    probe = irl.IpuScene(d).set_option("full_stats", 1).set_option("kernel", 0)     # created AFTER `plain`
+    monkeypatch.setenv("MI_RAYLIB_FULL_STATS", "1")                                 # the environment is read at create time only ...
+    other = irl.IpuScene(d).set_option("kernel", 2)
+    monkeypatch.delenv("MI_RAYLIB_FULL_STATS")
+    for dev, counted in ((plain, False), (probe, True), (other, True), (plain, False)):
+        dev.reset_counters()
+        got = s.init_ray_stream(); dev.run(got, irl.MODE_PATH_TRACE)
+        assert_streams_identical(got, want, "per-scene options")
+        c = dev.counters()
+        assert c["casts"] == st.casts
+        # ... so only the instrumented scenes count nodes, whatever was created or set in between
+        assert (c["nodes_visited"] == st.nodesVisited) if counted else (c["nodes_visited"] == 0)
+    with pytest.raises(irl.RaylibError, match="unknown option"):
+        plain.set_option("no_such_option", 1)
+    plain.close(); probe.close(); other.close()
+
+
+def test_one_scene_on_two_streams_concurrently(scenes):
+    """mi_render_device on two HIP streams of ONE scene: each stream owns its work counter and partial-sum buffer
+    (LaunchSlot), so two segmented renders in flight together both equal the oracle."""
+    import torch
+    s = scenes["box"]; d = s.desc
+    d.set_image(200, 120); d.samples_per_pixel = 100; d.path_trace = 1
+    dev = irl.IpuScene(d)
+    host = s.init_ray_stream(); want = host.copy()
+    ol.path_trace_pixel_rng(d, want, 16)
+    raw = torch.from_numpy(host.view(np.uint8).reshape(host.size, -1).copy())
+    bufs = [raw.cuda(), raw.cuda()]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for b, st in zip(bufs, streams):
+            b.copy_(raw, non_blocking=False)
+        torch.cuda.synchronize()
+        for b, st in zip(bufs, streams):
+            dev.run_device(b.data_ptr(), host.size, irl.MODE_PATH_TRACE, st.cuda_stream)
+        torch.cuda.synchronize()
+        for b in bufs:
+            got = np.frombuffer(b.cpu().numpy().tobytes(), dtype=irl.TRACE_RESULT)
+            assert_streams_identical(got, want, "two streams of one scene")
+    dev.close()
+    d.set_image(96, 64); d.samples_per_pixel = 5

@@ -31,26 +31,96 @@ def test_padding_rule_matches_reference_unit_test_property():
     assert lib.mi_blob_padding(16, 5, 4) == 3 and lib.mi_blob_padding(16, 6, 2) == 0 and lib.mi_blob_padding(2, 0, 4) == 2
 
 
-def _numpy_pack(desc, host):
-    """Independent packer: u32 count, pad to element alignment, raw element bytes; then the eight scalars."""
+# alignof() of every element type the SceneRef serialiser writes, each taken from the reference declaration it cites
+# (Serialiser::write(const T*, n) pads an array to alignof(T), include/serialisation/Serialiser.hpp:33-60).
+REF_ALIGN = {
+    "GeomRef": 2,           # include/Scene.hpp:29-34          u16 index + u8 type + u8 pad
+    "MeshInfo": 4,          # include/Mesh.hpp:15-20           4 x u32
+    "Triangle": 2,          # include/Primitives.hpp:21-25     packed, aligned(alignof(uint16_t))
+    "Vec3fa": 4,            # include/embree_utils/geometry.hpp:25-27   VEC3_ALIGN 4
+    "u32": 4,
+    "Material": 4,          # include/Material.hpp:8-35        Vec3fa, float, Vec3fa, enum, bool
+    "CompactBVH2Node": 8,   # include/CompactBVH2Node.hpp:52-53  __attribute__((aligned(8)))
+}
+
+
+def _numpy_pack(desc, host, layout=None):
+    """Independent packer: u32 count, pad to element alignment, raw element bytes; then the eight scalars.
+    `layout`, when given, receives {array name: (offset of the count, pad bytes, offset of the first element)}."""
     out = bytearray()
 
-    def arr(a, align):
+    def arr(name, a, elem):
+        out.extend(b"\0" * _pad(16, len(out), REF_ALIGN["u32"]))      # `s << size` is a u32 write (serialisation.hpp:21-32)
+        at = len(out)
         out.extend(struct.pack("<I", len(a)))
-        out.extend(b"\0" * _pad(16, len(out), align))
+        pad = _pad(16, len(out), REF_ALIGN[elem])
+        out.extend(b"\0" * pad)
+        if layout is not None:
+            layout[name] = (at, pad, len(out))
         out.extend(np.ascontiguousarray(a).tobytes())
 
     def scalar(fmt, v):
         out.extend(b"\0" * _pad(16, len(out), 4))
         out.extend(struct.pack(fmt, v))
 
-    arr(host.geometry, 2); arr(host.mesh_info, 4); arr(host.tris.reshape(-1, 3), 2); arr(host.verts, 4)
+    arr("geometry", host.geometry, "GeomRef"); arr("meshInfo", host.mesh_info, "MeshInfo")
+    arr("meshTris", host.tris.reshape(-1, 3), "Triangle"); arr("meshVerts", host.verts, "Vec3fa")
     normals = np.frombuffer(C.string_at(desc.mesh_normals, desc.num_normals * 12), np.float32) if desc.num_normals else np.zeros(0, np.float32)
-    arr(normals.reshape(-1, 3), 4); arr(host.mat_ids, 4); arr(host.materials, 4); arr(host.nodes, 4)
+    arr("meshNormals", normals.reshape(-1, 3), "Vec3fa"); arr("matIDs", host.mat_ids, "u32")
+    arr("materials", host.materials, "Material"); arr("bvhNodes", host.nodes, "CompactBVH2Node")
     scalar("<I", desc.max_leaf_depth); scalar("<f", desc.image_width); scalar("<f", desc.image_height)
     scalar("<f", desc.fov_radians); scalar("<f", desc.anti_alias_scale); scalar("<I", desc.max_path_length)
     scalar("<I", desc.roulette_start_depth); scalar("<I", desc.samples_per_pixel)
     return bytes(out)
+
+
+def _soup_scene(num_tris, num_materials):
+    """A small triangle soup with a chosen triangle and material count (both move the node array's offset)."""
+    rng = np.random.default_rng(num_tris * 31 + num_materials)
+    verts = (rng.random((3 * num_tris, 3), np.float32) * 4 - 2).astype(np.float32)
+    verts[:, 2] -= 6
+    tri = np.arange(3 * num_tris, dtype=np.uint16).reshape(-1, 3)
+    g = irl.SceneDesc()
+    geom = np.zeros(1, irl.GEOM_REF); mesh = np.zeros(1, irl.MESH_INFO)
+    mesh["numTriangles"] = num_tris; mesh["numVertices"] = 3 * num_tris
+    mats = np.zeros(num_materials, irl.MATERIAL); mat_ids = np.zeros(1, np.uint32)
+    g.geometry = geom.ctypes.data; g.num_geometry = 1
+    g.mesh_info = mesh.ctypes.data; g.num_meshes = 1
+    g.mesh_tris = tri.ctypes.data; g.num_tris = num_tris
+    g.mesh_verts = verts.ctypes.data; g.num_verts = 3 * num_tris
+    g.mat_ids = mat_ids.ctypes.data; g.num_mat_ids = 1
+    g.materials = mats.ctypes.data; g.num_materials = num_materials
+    s = irl.HostScene.from_arrays(g)
+    s._keep = (geom, mesh, tri, verts, mats, mat_ids)
+    return s
+
+
+def test_node_array_is_padded_to_the_reference_alignment_of_8():
+    """CompactBVH2Node is __attribute__((aligned(8))) (include/CompactBVH2Node.hpp:52-53), so the serialiser puts
+    4 pad bytes between the node count and the first node whenever the count ends on an offset that is 4 mod 8
+    (Serialiser.hpp:33-60), and the deserialiser skips them (deserialisation.hpp:31-38). Both cases are built here
+    (a 36-byte Material more or less flips the residue) and checked byte by byte."""
+    seen = set()
+    for num_materials in (1, 2, 3, 4):
+        s = _soup_scene(5, num_materials)
+        layout = {}
+        want = _numpy_pack(s.desc, s, layout)
+        blob = irl.serialise_scene(s.desc)
+        count_at, pad, first = layout["bvhNodes"]
+        assert pad == (8 - (16 + count_at + 4) % 8) % 8 and pad in (0, 4)
+        assert first % 8 == 0                                       # (the blob itself is 16-byte aligned)
+        seen.add(pad)
+        got = blob.tobytes()
+        assert got == want
+        assert len(got) == irl.host_lib().mi_scene_blob_size(C.byref(s.desc))
+        assert got[count_at:count_at + 4] == struct.pack("<I", s.nodes.size)
+        assert got[count_at + 4:first] == b"\0" * pad
+        assert got[first:first + 24 * s.nodes.size] == s.nodes.tobytes()
+        out = irl.deserialise_scene(blob)
+        assert C.cast(out.bvh_nodes, C.c_void_p).value == blob.ctypes.data + first
+        assert out.num_nodes == s.nodes.size and out.max_leaf_depth == s.desc.max_leaf_depth
+        assert out.samples_per_pixel == s.desc.samples_per_pixel
+    assert seen == {0, 4}, "both residues of the node array's offset must be exercised"
 
 
 @pytest.mark.parametrize("name", ["box-simple", "box", "spheres"])
