@@ -280,7 +280,8 @@ def main():
     if not args.no_extras and world == 1:
         # ---------------- K3, the NIF MLP on MFMA: 1440^2 rays, synthetic weights of the reference's shapes ----------------
         ks, bs, relu, dims = nif_weights(np.random.default_rng(0))
-        ns = irl.IpuScene(irl.HostScene.builtin("spheres").desc)
+        nif_scene = irl.HostScene.builtin("spheres")          # (kept alive: the desc points into it)
+        ns = irl.IpuScene(nif_scene.desc)
         ns.setNif(ks, bs, relu, 12, 3.43, np.array([-2.35, -2.27, -1.96], np.float32), True)
         nr = 1440 * 1440
         u = torch.rand(nr, device="cuda"); v = torch.rand(nr, device="cuda"); bgr = torch.empty(nr, 3, device="cuda")
