@@ -15,6 +15,7 @@
 #include "ray_math.h"
 #include "trace_kernels.hpp"
 #include "trace_wavefront.hpp"
+#include "trace_pool.hpp"
 #include "nif_kernels.hpp"
 #include "scene_blob.hpp"
 
@@ -78,7 +79,9 @@ const float* hostSinTable() {
 struct SceneOptions {
   bool fullStats = false;          // MI_RAYLIB_FULL_STATS / "full_stats": instrumented kernel variants (node/leaf counters, phase occupancy)
   WaveTune tune = {8, 16, 24, 48, 3};
-  int kernelChoice = 1;            // MI_RAYLIB_KERNEL / "kernel": 0 = nested-loop kernel, 1 = wavefront (global nodes), 2 = wavefront + LDS-staged nodes
+  int kernelChoice = 1;            // MI_RAYLIB_KERNEL / "kernel": 0 = nested-loop kernel, 1 = wavefront (global nodes), 2 = wavefront + LDS-staged nodes, 3 = path pool (trace_pool.hpp)
+  PoolTune poolTune;               // MI_RAYLIB_POOL_TUNE / "pool_tune": leafAt,burst,retireAt,refillMin,shadeW,genW[,dbl,maxExtra,leafThenNode,prio]
+  int poolSlots = 104;             // MI_RAYLIB_POOL_SLOTS / "pool_slots": path slots per wave, 96 | 104 (4 waves per SIMD) | 128 (3 waves per SIMD)
   int wavesPerSimd = 5;            // MI_RAYLIB_WAVES / "waves": 4 = the 108-VGPR build of the default kernel
   bool tiles = true;               // MI_RAYLIB_NO_TILES / "tiles": walk row-structured streams in 8x8 pixel tiles
   size_t segBudgetKb = (size_t)8 * 1024 * 1024;   // MI_RAYLIB_SEG_BUDGET_KB / "seg_budget_kb": partial-sum buffer budget per launch
@@ -89,7 +92,13 @@ struct SceneOptions {
   bool set(const std::string& key, const char* v) {
     if (!v) return false;
     if (key == "full_stats") fullStats = v[0] == '1';
-    else if (key == "kernel") kernelChoice = (v[0] == '0') ? 0 : (v[0] == '2') ? 2 : 1;
+    else if (key == "kernel") kernelChoice = (v[0] == '0') ? 0 : (v[0] == '2') ? 2 : (v[0] == '3') ? 3 : 1;
+    else if (key == "pool_slots") { const int q = atoi(v); if (q != 96 && q != 104 && q != 128) return false; poolSlots = q; }
+    else if (key == "pool_tune") {
+      unsigned a, b, c, d, e, f, db = 4, mx = 5, ln = 1, pr = 1;
+      if (sscanf(v, "%u,%u,%u,%u,%u,%u,%u,%u,%u,%u", &a, &b, &c, &d, &e, &f, &db, &mx, &ln, &pr) < 6) return false;
+      poolTune = {a, b, c ? c : 1, d ? d : 1, e, f, db ? db : 65, mx, ln, pr};
+    }
     else if (key == "waves") wavesPerSimd = (v[0] == '4') ? 4 : 5;
     else if (key == "tiles") tiles = v[0] != '0';
     else if (key == "seg_budget_kb") segBudgetKb = std::max<size_t>((size_t)strtoull(v, nullptr, 10), 1);
@@ -106,7 +115,8 @@ struct SceneOptions {
   void fromEnvironment() {
     static const char* const map[][2] = {{"MI_RAYLIB_FULL_STATS", "full_stats"}, {"MI_RAYLIB_KERNEL", "kernel"}, {"MI_RAYLIB_WAVES", "waves"},
                                          {"MI_RAYLIB_SEG_BUDGET_KB", "seg_budget_kb"}, {"MI_RAYLIB_NIF_SPL", "nif_spl"}, {"MI_RAYLIB_PIN", "pin"},
-                                         {"MI_RAYLIB_NIF_SHAPE", "nif_shape"}, {"MI_RAYLIB_TUNE", "tune"}};
+                                         {"MI_RAYLIB_NIF_SHAPE", "nif_shape"}, {"MI_RAYLIB_TUNE", "tune"},
+                                         {"MI_RAYLIB_POOL_TUNE", "pool_tune"}, {"MI_RAYLIB_POOL_SLOTS", "pool_slots"}};
     for (const auto& m : map) if (const char* e = getenv(m[0])) (void)set(m[1], e);
     if (getenv("MI_RAYLIB_NO_TILES")) tiles = false;
   }
@@ -121,10 +131,12 @@ struct LaunchSlot {
   hipStream_t stream = nullptr;
   uint32_t* d_workCounter = nullptr;
   float* d_segPart = nullptr; size_t segPartFloats = 0;     // [segments][n][3]
+  uint32_t* d_poolScratch = nullptr; size_t poolScratchWords = 0;   // kernel 3: [PG_WORDS][slots of the grid]
 };
 
 struct mi_scene {
   int device = 0;
+  int numCUs = 256;
   mi_scene_desc params{};            // scalar parameters only (pointers nulled)
   DeviceScene ds{};
   SceneOptions opt;
@@ -158,7 +170,7 @@ struct mi_scene {
     if (d_slotColor) (void)hipFree(d_slotColor);
     if (d_slotTp) (void)hipFree(d_slotTp);
     if (d_segTotal) (void)hipFree(d_segTotal);
-    for (LaunchSlot& l : slots) { if (l.d_workCounter) (void)hipFree(l.d_workCounter); if (l.d_segPart) (void)hipFree(l.d_segPart); }
+    for (LaunchSlot& l : slots) { if (l.d_workCounter) (void)hipFree(l.d_workCounter); if (l.d_segPart) (void)hipFree(l.d_segPart); if (l.d_poolScratch) (void)hipFree(l.d_poolScratch); }
     for (int i = 0; i < 2; ++i) { if (d_batch[i]) (void)hipFree(d_batch[i]); if (pipeStream[i]) (void)hipStreamDestroy(pipeStream[i]); }
     if (nifDone) (void)hipEventDestroy(nifDone);
     nif.release();
@@ -381,7 +393,23 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
     HIP_CHECK(hipMemsetAsync(workCounter, 0, sizeof(uint32_t), stream));
     const uint64_t items = (uint64_t)cnt * ((segmented || !plain) ? exs.segments : 1u);     // work atoms of this launch
     if (items > kMaxWorkItems) throw ArgError("mi_render: too many work items for one launch (cut the stream with mi_scene_set_ray_batch)");
-    if (plain && S.opt.kernelChoice == 2 && S.ds.numNodes > 0) {
+    if (S.opt.kernelChoice == 3 && S.ds.samplesPerPixel <= kPoolMaxSamples && S.ds.maxPathLength <= kPoolMaxBounces) {
+      // path pool (trace_pool.hpp): persistent, exactly as many workgroups as stay resident; each wave owns P slots
+      const int P = S.opt.poolSlots;
+      const uint32_t wgsPerCU = (P == 128) ? 3u : 4u;
+      const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 4u * P - 1) / (4u * P), (uint64_t)S.numCUs * wgsPerCU);
+      const uint32_t stride = blocks * 4u * (uint32_t)P;
+      const size_t need = (size_t)PG_WORDS * stride;
+      if (slot.poolScratchWords < need) {
+        if (slot.d_poolScratch) { HIP_CHECK(hipStreamSynchronize(stream)); (void)hipFree(slot.d_poolScratch); }
+        slot.d_poolScratch = nullptr; slot.poolScratchWords = 0;
+        HIP_CHECK(hipMalloc(&slot.d_poolScratch, need * sizeof(uint32_t)));
+        slot.poolScratchWords = need;
+      }
+#define MI_POOL_LAUNCH(PP, WPS) hipLaunchKernelGGL((path_trace_pool_kernel<STATS, PP, WPS>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, S.opt.poolTune, tileW, exs, slot.d_poolScratch, stride)
+      if (P == 96) MI_POOL_LAUNCH(96, 4); else if (P == 128) MI_POOL_LAUNCH(128, 3); else MI_POOL_LAUNCH(104, 4);
+#undef MI_POOL_LAUNCH
+    } else if (plain && S.opt.kernelChoice == 2 && S.ds.numNodes > 0) {
       // one 1024-thread workgroup per CU shares one LDS copy of the first nodes of the (preorder) array
       const uint32_t ldsNodes = std::min<uint32_t>(S.ds.numNodes, kLdsBudgetBytes / (uint32_t)sizeof(GNode));
       const size_t ldsBytes = (size_t)ldsNodes * sizeof(GNode);
@@ -489,6 +517,7 @@ int mi_scene_create(const mi_scene_desc* desc, mi_scene** out) {
     HIP_CHECK(hipSetDevice(desc->device));
     S = new mi_scene;
     S->device = desc->device;
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, desc->device) == hipSuccess && cus > 0) S->numCUs = cus; }
     S->params = *desc;
     buildDeviceScene(*S, *desc);
     // the caller's arrays are not referenced after this point

@@ -1,0 +1,498 @@
+// trace_pool.hpp — K1p: the path-trace hot loop with the paths DECOUPLED from the lanes.
+//
+// Why (profiles/r01_final_pmc.csv, tools/phase_probe.py on K1w): in the phase-scheduled kernel every lane owns one
+// path, so a NODE turn runs with the 56 % of the lanes whose path happens to be walking the BVH; the others wait for
+// a SHADE turn (46 % of the idle lanes), a primitive test (27 %) or a GEN turn (6 %), and SHADE / GEN themselves run
+// with 70 % / 32 % of the lanes. Here a wave owns a POOL of P > 64 path slots and its 64 lanes are workers:
+//   * a slot's state lives in LDS (ray + hit record 11 words, RNG 4, radiance 3, throughput 3, counters 1, pixel 1;
+//     [word][slot] so a wave's accesses spread over the banks) and, for what is touched once per path or less
+//     (the work unit's rgb sum, the last hit's normal and leaf for the AOVs), in an L2-resident scratch array;
+//   * four wave-private rings of slot numbers - READY (ray waits for a traversal lane), SHADE (traversal finished),
+//     GEN (next sample's camera ray), FETCH (work unit finished) - whose heads and counts are wave-uniform scalars:
+//     no atomics, no barriers, no other wave ever touches them;
+//   * a lane that finishes a traversal RETIRES it (5 words to the slot, slot number to the SHADE ring) and REFILLS
+//     itself from the READY ring (9 words), so NODE turns stay nearly full; SHADE and GEN turns pop up to 64 slots
+//     from their rings and run full as long as the rings are; the traversal state of the lanes (their own rays) just
+//     stays in registers across those turns.
+// Every path still performs exactly the reference's sequence of operations, in the reference's order, with the same
+// arithmetic (the blocks below are those of trace_wavefront.hpp, cited there line by line); only WHICH lane executes
+// a step, and when, changes - so every byte of every TraceResult stays equal to the oracle's.
+#pragma once
+
+#include "trace_wavefront.hpp"
+
+namespace mi {
+
+// Scheduling of one wave (all counts in lanes / slots; weights are quarter units, traversal weighs 4 per lane):
+//   leafAt        inside a traversal burst a LEAF turn runs when cL * leafAt > cN * 4
+//   burst         at most this many NODE/LEAF steps before the wave looks at its rings again
+//   retireAt      ... or earlier, once this many lanes have finished their traversal
+//   refillMin     free lanes are refilled from the READY ring when at least this many can be served
+//   shadeW, genW  top-level vote: SHADE / GEN run when min(ring, 64) * weight exceeds (lanes walking) * 4
+//   dbl, maxExtra, leafThenNode, prio   as in WaveTune
+struct PoolTune { uint32_t leafAt = 4, burst = 48, retireAt = 12, refillMin = 8, shadeW = 4, genW = 4, dbl = 4, maxExtra = 5, leafThenNode = 1, prio = 1; };
+
+enum : uint32_t { PP_NODE = 0, PP_LEAF = 1, PP_FIN = 2, PP_FREE = 3 };
+
+// LDS words of a slot
+enum : uint32_t {
+  PW_O = 0, PW_D = 3, PW_INV = 6, PW_SX = 9, PW_SY = 10,                  // the ray as the traversal wants it
+  PW_HT = 6, PW_HLEAF = 7, PW_HB0 = 8, PW_HB1 = 9, PW_HB2 = 10,           // ... overwritten by the hit when it retires
+  PW_RNG = 11, PW_COLOR = 15, PW_TP = 18, PW_CNT = 22, PW_PIX = 21, PW_WORDS = 23
+};
+// scratch words of a slot (global memory, [word][slot of the whole grid])
+enum : uint32_t { PG_RGB = 0, PG_NRM = 3, PG_LEAF = 6, PG_WORDS = 7 };
+// PW_CNT: sample 0..18 | bounce 19..26 | flags 27..28 | kz 29..30 | exactSlab 31
+constexpr uint32_t kPoolMaxSamples = (1u << 19) - 1u, kPoolMaxBounces = 255u;
+constexpr int kPoolQueueCap = 128;
+
+template <bool STATS, int P, int WAVES_PER_SIMD>
+__global__ void __launch_bounds__(256, WAVES_PER_SIMD) path_trace_pool_kernel(DeviceScene sc, mi_trace_result* rays, uint32_t n, uint32_t* workCounter, PoolTune tune,
+                                                                              uint32_t tileStreamW, WaveExtras ex, uint32_t* scratch, uint32_t scratchStride) {
+  static_assert(P >= 64 && P <= kPoolQueueCap, "pool size");
+  constexpr uint32_t QM = kPoolQueueCap - 1;
+  __shared__ float sinTbl[92];
+  __shared__ uint32_t poolLds[4][PW_WORDS * P];
+  __shared__ uint8_t ringLds[4][4][kPoolQueueCap];
+  load_sin_table(sinTbl);
+
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t* const wp = poolLds[wave];
+  uint8_t* const qReady = ringLds[wave][0]; uint8_t* const qShade = ringLds[wave][1];
+  uint8_t* const qGen = ringLds[wave][2]; uint8_t* const qFetch = ringLds[wave][3];
+  const uint32_t gslotBase = (blockIdx.x * 4u + wave) * (uint32_t)P;
+  auto SU = [&](uint32_t w, uint32_t s) -> uint32_t& { return wp[w * (uint32_t)P + s]; };
+  auto SF = [&](uint32_t w, uint32_t s) -> float& { return reinterpret_cast<float*>(wp)[w * (uint32_t)P + s]; };
+  auto GU = [&](uint32_t w, uint32_t s) -> uint32_t& { return scratch[(size_t)w * scratchStride + gslotBase + s]; };
+  auto GF = [&](uint32_t w, uint32_t s) -> float& { return reinterpret_cast<float*>(scratch)[(size_t)w * scratchStride + gslotBase + s]; };
+  // everything a turn wrote for later turns (other lanes of this wave will read it) has landed
+  auto turnFence = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); };
+  auto lanesBelow = [&](unsigned long long m) -> uint32_t { return (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); };
+
+  const uint32_t fetchChunk = ex.fetchChunk ? ex.fetchChunk : 64u;
+  uint32_t chunkNext = 0, chunkEnd = 0;
+  const uint32_t tiledCount = tileStreamW ? (n / (8u * tileStreamW)) * (8u * tileStreamW) : 0u;
+  const uint32_t numNodes = sc.numNodes;
+  const uint32_t spp = ex.sampleCount ? ex.sampleCount : sc.samplesPerPixel;
+  const bool segd = ex.segPart != nullptr || ex.slotColor != nullptr;
+  const uint32_t segShift = segment_shift(sc.samplesPerPixel), segMask = (1u << segShift) - 1u;
+  const uint32_t segs = segd ? ex.segments : 1u;
+  const uint32_t items = n * segs;
+
+  // ---- rings (wave-uniform heads and counts) ----
+  uint32_t hR = 0, nR = 0, hS = 0, nS = 0, hG = 0, nG = 0, hF = 0, nF = (uint32_t)P;
+  for (uint32_t i = lane; i < (uint32_t)P; i += 64u) qFetch[i] = (uint8_t)i;
+  bool drained = false;                            // wave-uniform: the work counter has passed the end of the launch
+  auto push = [&](uint8_t* q, uint32_t& head, uint32_t& count, bool p, uint32_t s) {
+    const unsigned long long m = __ballot(p);
+    if (p) q[(head + count + lanesBelow(m)) & QM] = (uint8_t)s;
+    count += (uint32_t)__popcll(m);
+  };
+
+  // ---- the lane's own traversal (its ray stays in registers across SHADE / GEN / FETCH turns) ----
+  uint32_t ph = PP_FREE, slot = 0, node = 0, pendLeaf = 0;
+  f3 o = mk(0, 0, 0), inv = mk(0, 0, 0);
+  Shear sh; sh.kz = 2; sh.sx = sh.sy = 0.f; sh.sz = 1.f;
+  Hit hit; hit.t = kInf; hit.leaf = 0xFFFFFFFFu; hit.geomID = 0xFFFFu; hit.b0 = hit.b1 = hit.b2 = 0.f;
+  bool exactSlab = false;
+
+  CastStats cs = {0, 0};
+  uint32_t casts = 0, paths = 0;
+  uint32_t itN = 0, itL = 0, itS = 0, itG = 0, lnN = 0, lnL = 0, lnS = 0, lnG = 0;
+  unsigned long long tTrav = 0, tShade = 0, tGen = 0, tLoop0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+
+  for (;;) {
+    // ---------------- FETCH: slots whose work unit is finished take the next (pixel, segment) unit ----------------
+    while (nF > 0 && !drained) {
+      if (chunkNext >= chunkEnd) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(workCounter, fetchChunk);
+        chunkNext = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        chunkEnd = chunkNext + fetchChunk;
+      }
+      const uint32_t take = min(min(nF, 64u), chunkEnd - chunkNext);
+      const bool mine = lane < take;
+      const uint32_t fs = mine ? (uint32_t)qFetch[(hF + lane) & QM] : 0u;
+      const uint32_t idx = chunkNext + lane;
+      hF = (hF + take) & QM; nF -= take; chunkNext += take;
+      const bool live = mine && idx < items;
+      if (live) {
+        // (the 8x8 tile walk of trace_wavefront.hpp: a bijection on [0, n), any order gives the same image)
+        uint32_t seg = 0, pidx = idx;
+        if (segd) { const uint32_t local = idx / n; pidx = idx - local * n; seg = ex.segBase + local; }
+        uint32_t entry = pidx;
+        if (tileStreamW && pidx < tiledCount) {
+          const uint32_t t = pidx >> 6, within = pidx & 63u, perRow = tileStreamW >> 3;
+          entry = ((t / perRow) * 8u + (within >> 3)) * tileStreamW + (t % perRow) * 8u + (within & 7u);
+        }
+        const mi_trace_result* res = rays + entry;
+        const float prow = res->u, pcol = res->v;
+        SU(PW_PIX, fs) = entry;
+        if (seg == 0) { GF(PG_RGB, fs) = res->rgb.x; GF(PG_RGB + 1, fs) = res->rgb.y; GF(PG_RGB + 2, fs) = res->rgb.z; }
+        else { GF(PG_RGB, fs) = 0.f; GF(PG_RGB + 1, fs) = 0.f; GF(PG_RGB + 2, fs) = 0.f; }
+        Rng rng;
+        rng_seed_pixel_segment(rng, sc.rngSeed, prow, pcol, seg);
+        SU(PW_RNG, fs) = (uint32_t)rng.s0; SU(PW_RNG + 1, fs) = (uint32_t)(rng.s0 >> 32);
+        SU(PW_RNG + 2, fs) = (uint32_t)rng.s1; SU(PW_RNG + 3, fs) = (uint32_t)(rng.s1 >> 32);
+        SU(PW_CNT, fs) = (ex.slotColor ? seg - ex.segBase : seg) << segShift;       // sample index; bounce, flags = 0
+      }
+      push(qGen, hG, nG, live, fs);
+      if (__ballot(mine && !live)) { drained = true; nF = 0; }          // indices past the end: the launch has no more work
+      turnFence();
+    }
+
+    // ---------------- what is there to do ----------------
+    uint32_t cN = (uint32_t)__popcll(__ballot(ph == PP_NODE)), cL = (uint32_t)__popcll(__ballot(ph == PP_LEAF));
+    const uint32_t cT = cN + cL;
+    if ((cT | nR | nS | nG | nF) == 0) break;
+
+    // ---------------- REFILL: free lanes take rays from the READY ring ----------------
+    {
+      const uint32_t canFill = min(nR, 64u - cT);
+      if (canFill > 0 && (canFill >= tune.refillMin || cT == 0 || (nS | nG) == 0)) {
+        const unsigned long long mF = __ballot(ph == PP_FREE);
+        const uint32_t rank = lanesBelow(mF);
+        if (ph == PP_FREE && rank < canFill) {
+          const uint32_t s = (uint32_t)qReady[(hR + rank) & QM];
+          slot = s;
+          o = mk(SF(PW_O, s), SF(PW_O + 1, s), SF(PW_O + 2, s));
+          inv = mk(SF(PW_INV, s), SF(PW_INV + 1, s), SF(PW_INV + 2, s));
+          sh.sx = SF(PW_SX, s); sh.sy = SF(PW_SY, s);
+          const uint32_t cnt = SU(PW_CNT, s);
+          sh.kz = (cnt >> 29) & 3u;
+          exactSlab = (cnt >> 31) != 0u;
+          sh.sz = comp(inv, sh.kz);                       // 1 / d[kz]: the same IEEE division (make_shear(d, inv))
+          hit.t = kInf; hit.leaf = 0xFFFFFFFFu;
+          node = 0;
+          ph = (numNodes > 0) ? PP_NODE : PP_FIN;
+        }
+        hR = (hR + canFill) & QM; nR -= canFill;
+        continue;
+      }
+    }
+
+    // ---------------- vote: walk, or serve a ring ----------------
+    uint32_t run;          // 0 = TRAVERSE, 2 = SHADE, 3 = GEN
+    {
+      const uint32_t wT = cT * 4u, wS = min(nS, 64u) * tune.shadeW, wG = min(nG, 64u) * tune.genW;
+      if (cT > 0 && wT >= max(wS, wG)) run = 0;
+      else run = (nS > 0 && wS >= wG) ? 2 : (nG > 0 ? 3 : (nS > 0 ? 2 : 0));
+    }
+
+    if (run == 0) {
+      // ---------------- TRAVERSE: NODE and LEAF steps under a two-way mini-vote (trace_wavefront.hpp) ----------------
+      const unsigned long long tq0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+      if (tune.prio == 1) __builtin_amdgcn_s_setprio(1);
+      uint32_t steps = 0;
+      const bool anyExact = __ballot(exactSlab && ph <= PP_LEAF) != 0ull;
+      auto nodeBodyT = [&](auto exactTag) -> bool {
+        GNode nd = *reinterpret_cast<const GNode*>(reinterpret_cast<const char*>(sc.nodes) + (node << 5));
+        if (STATS) cs.nodes++;
+        // Box test (CompactBVH2Node.cpp:5-22, intersectRaySlab CompactBVH2Node.hpp:14-50); min/max form and the
+        // literal fallback exactly as in trace_wavefront.hpp
+        const float ax = (nd.minx - o.x) * inv.x, bx = (nd.maxx - o.x) * inv.x;
+        const float ay = (nd.miny - o.y) * inv.y, by = (nd.maxy - o.y) * inv.y;
+        const float az = (nd.minz - o.z) * inv.z, bz = (nd.maxz - o.z) * inv.z;
+        float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
+        float t1 = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * kSlabScale, hit.t);
+        if constexpr (decltype(exactTag)::value) {
+          if (exactSlab) {
+            t0 = 0.f; t1 = hit.t;
+            { float tmin = ax, tmax = bx; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
+            { float tmin = ay, tmax = by; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
+            { float tmin = az, tmax = bz; if (tmin > tmax) { const float s = tmin; tmin = tmax; tmax = s; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
+          }
+        }
+        const bool boxHit = !(t0 > t1);
+        const bool isLeaf = nd.geomID != 0xFFFFu;
+        pendLeaf = nd.link;
+        if (boxHit && isLeaf) { ph = PP_LEAF; return false; }
+        node = (boxHit || isLeaf) ? node + 1 : nd.link;
+        if (node >= numNodes) { ph = PP_FIN; return false; }
+        return true;
+      };
+      auto nodeBody = [&]() -> bool { return nodeBodyT(std::false_type{}); };
+      auto nodeStep = [&]() { if (ph == PP_NODE) (void)(anyExact ? nodeBodyT(std::true_type{}) : nodeBodyT(std::false_type{})); };
+      for (;;) {
+        const uint32_t stay = cN;
+        if (cN * 4u >= cL * tune.leafAt && cN > 0) {
+          if (STATS) { itN++; lnN += stay; }
+          const uint32_t extra = min(stay / tune.dbl, tune.maxExtra);
+          if (STATS) {
+            nodeStep();
+            for (uint32_t e = 0; e < extra; ++e) { itN++; lnN += (uint32_t)__popcll(__ballot(ph == PP_NODE)); nodeStep(); }
+          } else if (anyExact) {
+            nodeStep();
+            for (uint32_t e = 0; e < extra; ++e) nodeStep();
+          } else if (ph == PP_NODE) {
+            bool go = nodeBody();
+            if (extra >= 1 && go) { go = nodeBody();
+              if (extra >= 2 && go) { go = nodeBody();
+                if (extra >= 3 && go) { go = nodeBody();
+                  if (extra >= 4 && go) { go = nodeBody();
+                    if (extra >= 5 && go) (void)nodeBody();
+                  }
+                }
+              }
+            }
+          }
+          steps += extra;
+        } else {
+          if (STATS) { itL++; lnL += cL; }
+          if (ph == PP_LEAF) {
+            if (STATS) cs.leaves++;
+            const GLeaf L = sc.leaves[pendLeaf];
+            float t, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+            bool cand;
+            const uint32_t kind = leaf_kind(L);
+            if (kind == LEAF_TRI) {
+              t = intersect_triangle(mk(L.f[0], L.f[1], L.f[2]), mk(L.f[3], L.f[4], L.f[5]), mk(L.f[6], L.f[7], L.f[8]), o, sh, b0, b1, b2);
+              cand = t > 0.f && t < kInf;
+            } else {
+              const f3 d = mk(SF(PW_D, slot), SF(PW_D + 1, slot), SF(PW_D + 2, slot));      // (only spheres and discs need the direction itself)
+              if (kind == LEAF_SPHERE) t = intersect_sphere(L, o, d, 0.f);
+              else t = intersect_disc(L, o, d);
+              cand = true;
+            }
+            if (cand && t > 0.f && t < hit.t) { hit.t = t; hit.leaf = pendLeaf; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2; }
+            node = node + 1;
+            ph = (node >= numNodes) ? PP_FIN : PP_NODE;
+          }
+          if (tune.leafThenNode) {
+            if (STATS) { itN++; lnN += (uint32_t)__popcll(__ballot(ph == PP_NODE)); }
+            nodeStep();
+            ++steps;
+          }
+        }
+        cN = (uint32_t)__popcll(__ballot(ph == PP_NODE));
+        cL = (uint32_t)__popcll(__ballot(ph == PP_LEAF));
+        if (++steps >= tune.burst || (cN + cL) == 0 || (cT - (cN + cL)) >= tune.retireAt) break;
+      }
+      if (tune.prio == 1) __builtin_amdgcn_s_setprio(0);
+      // ---- RETIRE: finished traversals hand their hit to the slot and queue it for shading ----
+      {
+        const bool fin = ph == PP_FIN;
+        if (fin) {
+          SF(PW_HT, slot) = hit.t; SU(PW_HLEAF, slot) = hit.leaf;
+          SF(PW_HB0, slot) = hit.b0; SF(PW_HB1, slot) = hit.b1; SF(PW_HB2, slot) = hit.b2;
+          ph = PP_FREE;
+        }
+        push(qShade, hS, nS, fin, slot);
+      }
+      turnFence();
+      if (STATS) tTrav += __builtin_amdgcn_s_memtime() - tq0;
+    } else if (run == 2) {
+      // ---------------- SHADE: up to 64 finished traversals (codelets/TraceCodelets.cpp:214-257) ----------------
+      const unsigned long long tq1 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+      const uint32_t k = min(nS, 64u);
+      if (STATS) { itS++; lnS += k; }
+      const bool mine = lane < k;
+      const uint32_t s = mine ? (uint32_t)qShade[(hS + lane) & QM] : 0u;
+      hS = (hS + k) & QM; nS -= k;
+      bool toReady = false, toGen = false, toFetch = false;
+      bool envRay = false;
+      uint32_t envSlot = 0;
+      f3 envDir = mk(0, 0, 0), envTp = mk(0, 0, 0);
+      if (mine) {
+        Hit h2; h2.t = SF(PW_HT, s); h2.leaf = SU(PW_HLEAF, s); h2.b0 = SF(PW_HB0, s); h2.b1 = SF(PW_HB1, s); h2.b2 = SF(PW_HB2, s); h2.geomID = 0xFFFFu;
+        f3 so = mk(SF(PW_O, s), SF(PW_O + 1, s), SF(PW_O + 2, s));
+        f3 sd = mk(SF(PW_D, s), SF(PW_D + 1, s), SF(PW_D + 2, s));
+        Rng rng;
+        rng.s0 = (uint64_t)SU(PW_RNG, s) | ((uint64_t)SU(PW_RNG + 1, s) << 32); rng.s1 = (uint64_t)SU(PW_RNG + 2, s) | ((uint64_t)SU(PW_RNG + 3, s) << 32);
+        f3 color = mk(SF(PW_COLOR, s), SF(PW_COLOR + 1, s), SF(PW_COLOR + 2, s));
+        f3 tp = mk(SF(PW_TP, s), SF(PW_TP + 1, s), SF(PW_TP + 2, s));
+        const uint32_t cnt = SU(PW_CNT, s);
+        uint32_t sample = cnt & kPoolMaxSamples, bounce = (cnt >> 19) & 0xFFu, oFlags = (cnt >> 27) & 3u;
+        const bool lastSample = sample + 1u >= spp;          // this path's final state is the pixel's AOV record
+        f3 nrm = mk(0.f, 0.f, 1.f);                          // HitRecord ctor, geometry.hpp:236-242
+        uint32_t lastLeaf = 0xFFFFFFFFu;
+        bool terminated = false;
+        const bool gotHit = h2.leaf != 0xFFFFFFFFu;
+        if (gotHit) {
+          const GLeaf L = sc.leaves[h2.leaf];
+          h2.geomID = leaf_geom(L);
+          lastLeaf = h2.leaf;
+          so = so + sd * h2.t;                                          // updateHit, Render.hpp:15-23
+          nrm = hit_normal(sc, h2, so);
+          const mi_material mat = sc.materials[L.matIndex];
+          const f3 albedo = mk(mat.albedo.x, mat.albedo.y, mat.albedo.z);
+          if (mat.emissive) color = color + tp * mk(mat.emission.x, mat.emission.y, mat.emission.z);
+          if (mat.type == 0) {
+            const float u1 = rng_uniform01(rng);
+            const float u2 = rng_uniform01(rng);
+            sd = sample_diffuse(nrm, u1, u2, sinTbl);
+            tp = tp * albedo;
+          } else if (mat.type == 1) {
+            sd = reflect_dir(sd, nrm);
+            tp = tp * albedo;
+          } else if (mat.type == 2) {
+            const float u1 = rng_uniform01(rng);
+            f3 nd2;
+            const bool refracted = dielectric(sd, nrm, mat.ior, u1, nd2);
+            sd = nd2;
+            if (refracted) tp = tp * albedo;
+          } else {
+            const float qn = __builtin_nanf("");
+            GF(PG_RGB, s) = GF(PG_RGB, s) * qn; GF(PG_RGB + 1, s) = GF(PG_RGB + 1, s) * qn; GF(PG_RGB + 2, s) = GF(PG_RGB + 2, s) * qn;
+            oFlags |= MI_FLAG_ERROR;
+          }
+        } else {
+          oFlags |= MI_FLAG_ESCAPED;
+          terminated = true;
+          if (lastSample && bounce > 0u) {                   // the AOVs keep the last HIT's normal and primitive
+            nrm = mk(GF(PG_NRM, s), GF(PG_NRM + 1, s), GF(PG_NRM + 2, s));
+            lastLeaf = GU(PG_LEAF, s);
+          }
+        }
+        if (!terminated && bounce > sc.rouletteStartDepth) {
+          const float u1 = rng_uniform01(rng);
+          if (roulette_stop(u1, tp)) terminated = true;
+        }
+        bounce++;
+        if (bounce >= sc.maxPathLength) terminated = true;
+        if (terminated) {
+          const uint32_t pixNow = SU(PW_PIX, s);
+          mi_trace_result* res = rays + pixNow;
+          f3 sum = mk(0, 0, 0);
+          if (ex.slotColor) {
+            const size_t q = (size_t)sample * n + pixNow;
+            ex.slotColor[3 * q] = color.x; ex.slotColor[3 * q + 1] = color.y; ex.slotColor[3 * q + 2] = color.z;
+            envRay = (oFlags & MI_FLAG_ESCAPED) != 0;
+            envSlot = (uint32_t)q;
+            envDir = sd; envTp = tp;
+            if (!envRay) ex.u[q] = -1.f;
+          } else {
+            sum = mk(GF(PG_RGB, s) + color.x, GF(PG_RGB + 1, s) + color.y, GF(PG_RGB + 2, s) + color.z);
+          }
+          ++paths;
+          ++sample;
+          const bool more = segd ? ((sample & segMask) != 0u && sample < spp) : (sample < spp);
+          if (more) {
+            if (!ex.slotColor) { GF(PG_RGB, s) = sum.x; GF(PG_RGB + 1, s) = sum.y; GF(PG_RGB + 2, s) = sum.z; }
+            SU(PW_RNG, s) = (uint32_t)rng.s0; SU(PW_RNG + 1, s) = (uint32_t)(rng.s0 >> 32);
+            SU(PW_RNG + 2, s) = (uint32_t)rng.s1; SU(PW_RNG + 3, s) = (uint32_t)(rng.s1 >> 32);
+            SU(PW_CNT, s) = sample;
+            toGen = true;
+          } else if (segd && sample < spp) {
+            // a segment other than the last is complete: its partial sum (or its slots) is all it leaves
+            if (ex.segPart) {
+              float* part = ex.segPart + 3 * ((size_t)(((sample - 1u) >> segShift) - ex.segBase) * n + pixNow);
+              part[0] = sum.x; part[1] = sum.y; part[2] = sum.z;
+            }
+            toFetch = true;
+          } else {
+            // pixel complete: rgb sum + the LAST sample's hit record
+            if (ex.segPart) {
+              float* part = ex.segPart + 3 * ((size_t)(((sample - 1u) >> segShift) - ex.segBase) * n + pixNow);
+              part[0] = sum.x; part[1] = sum.y; part[2] = sum.z;
+            } else if (!ex.slotColor) res->rgb = {sum.x, sum.y, sum.z};
+            uint32_t oPrim = MI_INVALID_PRIM, oGeom = MI_INVALID_GEOM;
+            if (lastLeaf != 0xFFFFFFFFu) { const GLeaf LL = sc.leaves[lastLeaf]; oPrim = LL.primID; oGeom = leaf_geom(LL); }
+            mi_hit_record hr;
+            hr.r.origin = {so.x, so.y, so.z}; hr.r.t_min = 0.f;
+            hr.r.direction = {sd.x, sd.y, sd.z}; hr.r.t_max = gotHit ? h2.t : kInf;
+            hr.prim_id = oPrim;
+            hr.normal = {nrm.x, nrm.y, nrm.z};
+            hr.throughput = {tp.x, tp.y, tp.z};
+            hr.geom_id = (uint16_t)oGeom; hr.flags = (uint16_t)oFlags;
+            res->h = hr;
+            toFetch = true;
+          }
+        } else {
+          // next bounce: offsetRay + cast set-up (codelets :207-211)
+          if (lastSample) { GF(PG_NRM, s) = nrm.x; GF(PG_NRM + 1, s) = nrm.y; GF(PG_NRM + 2, s) = nrm.z; GU(PG_LEAF, s) = lastLeaf; }
+          so = offset_origin(so, sd, nrm);
+          const f3 si = mk(1.f / sd.x, 1.f / sd.y, 1.f / sd.z);
+          const bool ex2 = !(fabsf(si.x) < kInf && fabsf(si.y) < kInf && fabsf(si.z) < kInf && fabsf(so.x) < kInf && fabsf(so.y) < kInf && fabsf(so.z) < kInf);
+          const Shear s2 = make_shear(sd, si);
+          SF(PW_O, s) = so.x; SF(PW_O + 1, s) = so.y; SF(PW_O + 2, s) = so.z;
+          SF(PW_D, s) = sd.x; SF(PW_D + 1, s) = sd.y; SF(PW_D + 2, s) = sd.z;
+          SF(PW_INV, s) = si.x; SF(PW_INV + 1, s) = si.y; SF(PW_INV + 2, s) = si.z;
+          SF(PW_SX, s) = s2.sx; SF(PW_SY, s) = s2.sy;
+          SU(PW_RNG, s) = (uint32_t)rng.s0; SU(PW_RNG + 1, s) = (uint32_t)(rng.s0 >> 32);
+          SU(PW_RNG + 2, s) = (uint32_t)rng.s1; SU(PW_RNG + 3, s) = (uint32_t)(rng.s1 >> 32);
+          SF(PW_COLOR, s) = color.x; SF(PW_COLOR + 1, s) = color.y; SF(PW_COLOR + 2, s) = color.z;
+          SF(PW_TP, s) = tp.x; SF(PW_TP + 1, s) = tp.y; SF(PW_TP + 2, s) = tp.z;
+          SU(PW_CNT, s) = sample | (bounce << 19) | (oFlags << 27) | (s2.kz << 29) | (ex2 ? 0x80000000u : 0u);
+          ++casts;
+          toReady = true;
+        }
+      }
+      if (ex.slotColor) {
+        const unsigned long long mE = __ballot(envRay);
+        if (mE) {
+          const uint32_t firstE = (uint32_t)__ffsll((long long)mE) - 1u;
+          uint32_t baseE = 0;
+          if (lane == firstE) baseE = atomicAdd(ex.count, (uint32_t)__popcll(mE));
+          baseE = __shfl(baseE, firstE);
+          if (envRay) {
+            // PreProcessEscapedRays (codelets/TraceCodelets.cpp:321-358), same arithmetic as escaped_uv_kernel
+            const float twoPi = (float)(2.0 * 3.14159265358979323846264338327950288);
+            const float invPi = (float)(1.0 / 3.14159265358979323846264338327950288);
+            const float inv2Pi = (float)(1.0 / (2.0 * 3.14159265358979323846264338327950288));
+            const float theta = acosf(envDir.y);
+            float phi = atan2f(envDir.z, envDir.x) + ex.azimuthRotation;
+            if (phi < 0.f) phi += twoPi;
+            else if (phi > twoPi) phi -= twoPi;
+            ex.u[envSlot] = theta * invPi;
+            ex.v[envSlot] = phi * inv2Pi;
+            ex.slotTp[3 * (size_t)envSlot] = envTp.x; ex.slotTp[3 * (size_t)envSlot + 1] = envTp.y; ex.slotTp[3 * (size_t)envSlot + 2] = envTp.z;
+            ex.index[baseE + lanesBelow(mE)] = envSlot;
+          }
+        }
+      }
+      push(qReady, hR, nR, toReady, s);
+      push(qGen, hG, nG, toGen, s);
+      if (!drained) push(qFetch, hF, nF, toFetch, s);      // (after the end of the launch a finished slot simply dies)
+      turnFence();
+      if (STATS) tShade += __builtin_amdgcn_s_memtime() - tq1;
+    } else {
+      // ---------------- GEN: camera rays of up to 64 next samples (codelets/TraceCodelets.cpp:142-164) ----------------
+      const unsigned long long tq2 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+      const uint32_t k = min(nG, 64u);
+      if (STATS) { itG++; lnG += k; }
+      const bool mine = lane < k;
+      const uint32_t s = mine ? (uint32_t)qGen[(hG + lane) & QM] : 0u;
+      hG = (hG + k) & QM; nG -= k;
+      if (mine) {
+        Rng rng;
+        rng.s0 = (uint64_t)SU(PW_RNG, s) | ((uint64_t)SU(PW_RNG + 1, s) << 32); rng.s1 = (uint64_t)SU(PW_RNG + 2, s) | ((uint64_t)SU(PW_RNG + 3, s) << 32);
+        const uint32_t sample = SU(PW_CNT, s) & kPoolMaxSamples;
+        const mi_trace_result* res = rays + SU(PW_PIX, s);
+        const float prow = res->u, pcol = res->v;
+        float g0, g1;
+        rng_gauss2(rng, sinTbl, g0, g1);
+        const float jr = prow + sc.antiAliasScale * g0, jc = pcol + sc.antiAliasScale * g1;
+        const f3 sd = pixel_to_ray_dir(jc, jr, sc.imageWidth, sc.imageHeight, sc.tanTheta);
+        const f3 so = offset_origin(mk(0.f, 0.f, 0.f), sd, mk(0.f, 0.f, 1.f));
+        const f3 si = mk(1.f / sd.x, 1.f / sd.y, 1.f / sd.z);
+        const bool ex2 = !(fabsf(si.x) < kInf && fabsf(si.y) < kInf && fabsf(si.z) < kInf && fabsf(so.x) < kInf && fabsf(so.y) < kInf && fabsf(so.z) < kInf);
+        const Shear s2 = make_shear(sd, si);
+        SF(PW_O, s) = so.x; SF(PW_O + 1, s) = so.y; SF(PW_O + 2, s) = so.z;
+        SF(PW_D, s) = sd.x; SF(PW_D + 1, s) = sd.y; SF(PW_D + 2, s) = sd.z;
+        SF(PW_INV, s) = si.x; SF(PW_INV + 1, s) = si.y; SF(PW_INV + 2, s) = si.z;
+        SF(PW_SX, s) = s2.sx; SF(PW_SY, s) = s2.sy;
+        SU(PW_RNG, s) = (uint32_t)rng.s0; SU(PW_RNG + 1, s) = (uint32_t)(rng.s0 >> 32);
+        SU(PW_RNG + 2, s) = (uint32_t)rng.s1; SU(PW_RNG + 3, s) = (uint32_t)(rng.s1 >> 32);
+        SF(PW_COLOR, s) = 0.f; SF(PW_COLOR + 1, s) = 0.f; SF(PW_COLOR + 2, s) = 0.f;
+        SF(PW_TP, s) = 1.f; SF(PW_TP + 1, s) = 1.f; SF(PW_TP + 2, s) = 1.f;
+        SU(PW_CNT, s) = sample | (s2.kz << 29) | (ex2 ? 0x80000000u : 0u);             // bounce 0, flags 0
+        ++casts;
+      }
+      push(qReady, hR, nR, mine, s);
+      turnFence();
+      if (STATS) tGen += __builtin_amdgcn_s_memtime() - tq2;
+    }
+  }
+  flush_stats(sc, casts, cs, paths);
+  if (STATS && lane == 0) {
+    atomicAdd(&sc.counters[4], (unsigned long long)itN); atomicAdd(&sc.counters[5], (unsigned long long)lnN);
+    atomicAdd(&sc.counters[6], (unsigned long long)itL); atomicAdd(&sc.counters[7], (unsigned long long)lnL);
+    atomicAdd(&sc.counters[8], (unsigned long long)itS); atomicAdd(&sc.counters[9], (unsigned long long)lnS);
+    atomicAdd(&sc.counters[10], (unsigned long long)itG); atomicAdd(&sc.counters[11], (unsigned long long)lnG);
+    atomicAdd(&sc.counters[12], tTrav); atomicAdd(&sc.counters[13], tShade); atomicAdd(&sc.counters[14], tGen);
+    atomicAdd(&sc.counters[15], __builtin_amdgcn_s_memtime() - tLoop0);
+  }
+}
+
+}  // namespace mi

@@ -142,7 +142,7 @@ def nif_campaign(budget, seed, max_cases=None):
             dev.close()
             return rays
 
-        literal, batched = render("0"), render("1")
+        literal, batched = render("0"), render(str(rng.choice(["1", "3"])))
         bad = differing(batched, literal)
         if bad.size:
             i = int(bad[0])
@@ -186,7 +186,7 @@ def campaign(budget=240.0, seed=1, scale=1, max_cases=None):
         d.roulette_start_depth = int(rng.integers(0, 7))
         mode = irl.MODE_PATH_TRACE if rng.random() < 0.8 else irl.MODE_SHADOW_TRACE
         d.path_trace = 1 if mode == irl.MODE_PATH_TRACE else 0
-        kernel = str(rng.choice(["0", "1", "1", "1", "2"]))
+        kernel = str(rng.choice(["0", "1", "1", "3", "3", "2"]))
         waves = str(rng.choice(["4", "5"]))
         batch = int(rng.integers(1, 4000)) if rng.random() < 0.25 else 0
         desc = (f"case {case} (seed {seed}): {what} {w}x{h} crop={crop} spp={spp} rngseed={d.rng_seed} aa={d.anti_alias_scale} "

@@ -80,17 +80,27 @@ def test_traversal_visits_exactly_the_reference_nodes(scenes):
 # ------------------------------------------------------------------------------------------------------
 # path trace: rgb sums + last-sample hit records, per-pixel RNG streams
 # ------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("kernel", ["0", "1", "1w4", "2"])
+def _with_kernel(dev, kernel):
+    """kernel strings: "0" | "1" | "1w4" | "2" | "3" | "3p96" | "3p128" (variant + waves / pool size)"""
+    dev.set_option("kernel", kernel[0])
+    if kernel.endswith("w4"):
+        dev.set_option("waves", 4)
+    if "p" in kernel:
+        dev.set_option("pool_slots", kernel.split("p")[1])
+    return dev
+
+
+@pytest.mark.parametrize("kernel", ["0", "1", "1w4", "2", "3", "3p96", "3p128"])
 @pytest.mark.parametrize("name,size,spp", [("box-simple", 128, 32), ("box", 160, 24), ("spheres", 128, 32)])
 def test_path_trace_bit_exact(scenes, name, size, spp, kernel):
     """kernel 0 = nested-loop kernel, 1 = phase-scheduled persistent kernel, 2 = the same with the BVH
-    prefix staged in LDS; 1 is built for 5 waves per SIMD (default) and for 4 ("1w4"). All of them must reproduce
-    the oracle bit for bit."""
+    prefix staged in LDS, 3 = the path-pool kernel (104, 96 or 128 slots per wave); 1 is built for 5 waves per SIMD
+    and for 4 ("1w4"). All of them must reproduce the oracle bit for bit."""
     s = scenes[name]
     s.desc.set_image(size, size)
     s.desc.path_trace = 1
     s.desc.samples_per_pixel = spp
-    dev = irl.IpuScene(s.desc).set_option("kernel", kernel[0]).set_option("waves", 4 if kernel.endswith("w4") else 5)
+    dev = _with_kernel(irl.IpuScene(s.desc), kernel)
     got = s.init_ray_stream(); want = got.copy()
     dev.run(got, irl.MODE_PATH_TRACE)
     st = ol.path_trace_pixel_rng(s.desc, want, 16)
@@ -570,6 +580,8 @@ def test_nif_render_sample_batching_is_order_exact(scenes, spl, spp):
     literal = render("0")
     batched = render("1")
     assert_streams_identical(batched, literal, f"NIF render, {spp} spp, {spl} samples per launch")
+    pooled = render("3")
+    assert_streams_identical(pooled, literal, f"NIF render with the path-pool kernel, {spp} spp, {spl} samples per launch")
     assert np.stack([batched["rgb"][k] for k in "xyz"], 1).max() > 0
 
 
@@ -604,7 +616,7 @@ def test_randomised_render_parameters_against_oracle(scenes):
         d.set_image(96, 64); d.anti_alias_scale = 0.25; d.max_path_length = 10; d.roulette_start_depth = 3; d.rng_seed = 1442
 
 
-@pytest.mark.parametrize("kernel,spp", [("0", 300), ("1", 300), ("2", 300), ("0", 700), ("1", 700), ("2", 700)])
+@pytest.mark.parametrize("kernel,spp", [("0", 300), ("1", 300), ("2", 300), ("3", 300), ("0", 700), ("1", 700), ("2", 700), ("3", 700), ("3p128", 700)])
 def test_segmented_pixels_bit_exact(scenes, kernel, spp):
     """More samples per pixel than one segment holds: the pixel is traced as segments (about sixteen per pixel, 4 to 64
     samples long), each with its own RNG stream and partial rgb sum, added in segment order.
@@ -614,7 +626,7 @@ def test_segmented_pixels_bit_exact(scenes, kernel, spp):
     for bit; so must a batched render (both pipeline slots, each with its own partial-sum buffer)."""
     s = scenes["box"]; d = s.desc
     d.set_image(72, 40); d.samples_per_pixel = spp; d.path_trace = 1
-    dev = irl.IpuScene(d).set_option("kernel", kernel)
+    dev = _with_kernel(irl.IpuScene(d), kernel)
     got = s.init_ray_stream()
     rng = np.random.default_rng(3)
     for k in "xyz":
