@@ -81,7 +81,7 @@ struct SceneOptions {
   WaveTune tune = {8, 16, 24, 48, 3};
   int kernelChoice = 1;            // MI_RAYLIB_KERNEL / "kernel": 0 = nested-loop kernel, 1 = wavefront (global nodes), 2 = wavefront + LDS-staged nodes, 3 = path pool (trace_pool.hpp)
   PoolTune poolTune;               // MI_RAYLIB_POOL_TUNE / "pool_tune": leafAt,burst,retireAt,refillMin,shadeW,genW[,dbl,maxExtra,leafThenNode,prio]
-  int poolSlots = 104;             // MI_RAYLIB_POOL_SLOTS / "pool_slots": path slots per wave, 96 | 104 (4 waves per SIMD) | 128 (3 waves per SIMD)
+  int poolWaves = 4;               // MI_RAYLIB_POOL_WAVES / "pool_waves": waves per workgroup of the path-pool kernel, 4 | 8 | 16 (400 | 800 | 1600 slots)
   int wavesPerSimd = 5;            // MI_RAYLIB_WAVES / "waves": 4 = the 108-VGPR build of the default kernel
   bool tiles = true;               // MI_RAYLIB_NO_TILES / "tiles": walk row-structured streams in 8x8 pixel tiles
   size_t segBudgetKb = (size_t)8 * 1024 * 1024;   // MI_RAYLIB_SEG_BUDGET_KB / "seg_budget_kb": partial-sum buffer budget per launch
@@ -93,7 +93,7 @@ struct SceneOptions {
     if (!v) return false;
     if (key == "full_stats") fullStats = v[0] == '1';
     else if (key == "kernel") kernelChoice = (v[0] == '0') ? 0 : (v[0] == '2') ? 2 : (v[0] == '3') ? 3 : 1;
-    else if (key == "pool_slots") { const int q = atoi(v); if (q != 96 && q != 104 && q != 128) return false; poolSlots = q; }
+    else if (key == "pool_waves") { const int q = atoi(v); if (q != 4 && q != 8 && q != 16) return false; poolWaves = q; }
     else if (key == "pool_tune") {
       unsigned a, b, c, d, e, f, db = 4, mx = 5, ln = 1, pr = 1;
       if (sscanf(v, "%u,%u,%u,%u,%u,%u,%u,%u,%u,%u", &a, &b, &c, &d, &e, &f, &db, &mx, &ln, &pr) < 6) return false;
@@ -116,7 +116,7 @@ struct SceneOptions {
     static const char* const map[][2] = {{"MI_RAYLIB_FULL_STATS", "full_stats"}, {"MI_RAYLIB_KERNEL", "kernel"}, {"MI_RAYLIB_WAVES", "waves"},
                                          {"MI_RAYLIB_SEG_BUDGET_KB", "seg_budget_kb"}, {"MI_RAYLIB_NIF_SPL", "nif_spl"}, {"MI_RAYLIB_PIN", "pin"},
                                          {"MI_RAYLIB_NIF_SHAPE", "nif_shape"}, {"MI_RAYLIB_TUNE", "tune"},
-                                         {"MI_RAYLIB_POOL_TUNE", "pool_tune"}, {"MI_RAYLIB_POOL_SLOTS", "pool_slots"}};
+                                         {"MI_RAYLIB_POOL_TUNE", "pool_tune"}, {"MI_RAYLIB_POOL_WAVES", "pool_waves"}};
     for (const auto& m : map) if (const char* e = getenv(m[0])) (void)set(m[1], e);
     if (getenv("MI_RAYLIB_NO_TILES")) tiles = false;
   }
@@ -143,6 +143,7 @@ struct mi_scene {
   std::vector<void*> allocations;
   unsigned long long* d_counters = nullptr;
   std::vector<LaunchSlot> slots;
+  bool poolAttrSet[2][3] = {{false, false, false}, {false, false, false}};
   bool ldsAttrSet[2] = {false, false};   // kernel 2's dynamic-LDS opt-in (plain / instrumented build), per scene and so per device: function attributes are per device
   hipEvent_t nifDone = nullptr; bool nifPending = false;
   // mi_render's pipeline: two device batch buffers and two streams, kept between calls
@@ -394,11 +395,11 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
     const uint64_t items = (uint64_t)cnt * ((segmented || !plain) ? exs.segments : 1u);     // work atoms of this launch
     if (items > kMaxWorkItems) throw ArgError("mi_render: too many work items for one launch (cut the stream with mi_scene_set_ray_batch)");
     if (S.opt.kernelChoice == 3 && S.ds.samplesPerPixel <= kPoolMaxSamples && S.ds.maxPathLength <= kPoolMaxBounces) {
-      // path pool (trace_pool.hpp): persistent, exactly as many workgroups as stay resident; each wave owns P slots
-      const int P = S.opt.poolSlots;
-      const uint32_t wgsPerCU = (P == 128) ? 3u : 4u;
-      const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 4u * P - 1) / (4u * P), (uint64_t)S.numCUs * wgsPerCU);
-      const uint32_t stride = blocks * 4u * (uint32_t)P;
+      // path pool (trace_pool.hpp): persistent, exactly as many workgroups as stay resident; a workgroup of W waves
+      // owns 100 W path slots
+      const uint32_t W = (uint32_t)S.opt.poolWaves, pwg = 100u * W;
+      const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + pwg - 1) / pwg, (uint64_t)S.numCUs * (16u / W));
+      const uint32_t stride = blocks * pwg;
       const size_t need = (size_t)PG_WORDS * stride;
       if (slot.poolScratchWords < need) {
         if (slot.d_poolScratch) { HIP_CHECK(hipStreamSynchronize(stream)); (void)hipFree(slot.d_poolScratch); }
@@ -406,9 +407,17 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
         HIP_CHECK(hipMalloc(&slot.d_poolScratch, need * sizeof(uint32_t)));
         slot.poolScratchWords = need;
       }
-#define MI_POOL_LAUNCH(PP, WPS) hipLaunchKernelGGL((path_trace_pool_kernel<STATS, PP, WPS>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, S.opt.poolTune, tileW, exs, slot.d_poolScratch, stride)
-      if (P == 96) MI_POOL_LAUNCH(96, 4); else if (P == 128) MI_POOL_LAUNCH(128, 3); else MI_POOL_LAUNCH(104, 4);
-#undef MI_POOL_LAUNCH
+      const size_t ldsBytes = pool_lds_bytes(pwg);
+      auto go = [&](auto kern, int which) {
+        if (!S.poolAttrSet[STATS ? 1 : 0][which]) {
+          HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+          S.poolAttrSet[STATS ? 1 : 0][which] = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * W), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, S.opt.poolTune, tileW, exs, slot.d_poolScratch, stride);
+      };
+      if (W == 4) go(path_trace_pool_kernel<STATS, 4, 400, 4>, 0);
+      else if (W == 8) go(path_trace_pool_kernel<STATS, 8, 800, 4>, 1);
+      else go(path_trace_pool_kernel<STATS, 16, 1600, 4>, 2);
     } else if (plain && S.opt.kernelChoice == 2 && S.ds.numNodes > 0) {
       // one 1024-thread workgroup per CU shares one LDS copy of the first nodes of the (preorder) array
       const uint32_t ldsNodes = std::min<uint32_t>(S.ds.numNodes, kLdsBudgetBytes / (uint32_t)sizeof(GNode));

@@ -3,17 +3,22 @@
 // Why (profiles/r01_final_pmc.csv, tools/phase_probe.py on K1w): in the phase-scheduled kernel every lane owns one
 // path, so a NODE turn runs with the 56 % of the lanes whose path happens to be walking the BVH; the others wait for
 // a SHADE turn (46 % of the idle lanes), a primitive test (27 %) or a GEN turn (6 %), and SHADE / GEN themselves run
-// with 70 % / 32 % of the lanes. Here a wave owns a POOL of P > 64 path slots and its 64 lanes are workers:
-//   * a slot's state lives in LDS (ray + hit record 11 words, RNG 4, radiance 3, throughput 3, counters 1, pixel 1;
-//     [word][slot] so a wave's accesses spread over the banks) and, for what is touched once per path or less
-//     (the work unit's rgb sum, the last hit's normal and leaf for the AOVs), in an L2-resident scratch array;
-//   * four wave-private rings of slot numbers - READY (ray waits for a traversal lane), SHADE (traversal finished),
-//     GEN (next sample's camera ray), FETCH (work unit finished) - whose heads and counts are wave-uniform scalars:
-//     no atomics, no barriers, no other wave ever touches them;
+// with 70 % / 32 % of the lanes. Here a WORKGROUP owns a pool of PWG path slots, more than it has lanes, and its
+// lanes are workers:
+//   * a slot's hot state lives in LDS (ray 11 words - overwritten by the 5-word hit record when the traversal
+//     retires -, RNG 4, radiance 3, throughput 3, counters 1; [word][slot]); what is touched once per path or less
+//     (pixel index and coordinates, the work unit's rgb sum, the last hit's normal and leaf for the AOVs) lives in an
+//     L2-resident scratch array. Both are shared by the waves of the workgroup, which all run on one CU: LDS
+//     operations of a wave execute in order, and workgroup-scope release / acquire fences order the rest (on gfx950
+//     they cost an s_waitcnt lgkmcnt(0): the CU's vector L1 is shared, no cache maintenance, no vmcnt wait);
+//   * four rings of slot numbers in LDS - READY (ray waits for a traversal lane), SHADE (traversal finished), GEN
+//     (next sample's camera ray), FETCH (work unit finished). A wave pushes with one ds_add on the ring's tail and
+//     plain stores, pops with one compare-and-swap on its head; an entry that has been reserved but not written yet
+//     reads as EMPTY and is simply re-read;
 //   * a lane that finishes a traversal RETIRES it (5 words to the slot, slot number to the SHADE ring) and REFILLS
-//     itself from the READY ring (9 words), so NODE turns stay nearly full; SHADE and GEN turns pop up to 64 slots
-//     from their rings and run full as long as the rings are; the traversal state of the lanes (their own rays) just
-//     stays in registers across those turns.
+//     itself from the READY ring (9 words): NODE turns stay nearly full. Whichever wave finds a full batch on the
+//     SHADE or GEN ring (and has fewer lanes walking than the batch holds) serves it with all 64 lanes; the rays its
+//     lanes were walking just stay in their registers meanwhile.
 // Every path still performs exactly the reference's sequence of operations, in the reference's order, with the same
 // arithmetic (the blocks below are those of trace_wavefront.hpp, cited there line by line); only WHICH lane executes
 // a step, and when, changes - so every byte of every TraceResult stays equal to the oracle's.
@@ -23,14 +28,14 @@
 
 namespace mi {
 
-// Scheduling of one wave (all counts in lanes / slots; weights are quarter units, traversal weighs 4 per lane):
+// Scheduling of one wave (all counts in lanes / slots; weights are quarter units, a walking lane weighs 4):
 //   leafAt        inside a traversal burst a LEAF turn runs when cL * leafAt > cN * 4
-//   burst         at most this many NODE/LEAF steps before the wave looks at its rings again
+//   burst         at most this many NODE/LEAF steps before the wave looks at the rings again
 //   retireAt      ... or earlier, once this many lanes have finished their traversal
 //   refillMin     free lanes are refilled from the READY ring when at least this many can be served
-//   shadeW, genW  top-level vote: SHADE / GEN run when min(ring, 64) * weight exceeds (lanes walking) * 4
+//   shadeW, genW  vote: SHADE / GEN are served when min(ring, 64) * weight exceeds (lanes walking) * 4
 //   dbl, maxExtra, leafThenNode, prio   as in WaveTune
-struct PoolTune { uint32_t leafAt = 4, burst = 48, retireAt = 12, refillMin = 8, shadeW = 4, genW = 4, dbl = 4, maxExtra = 5, leafThenNode = 1, prio = 1; };
+struct PoolTune { uint32_t leafAt = 4, burst = 48, retireAt = 16, refillMin = 8, shadeW = 4, genW = 4, dbl = 4, maxExtra = 5, leafThenNode = 1, prio = 1; };
 
 enum : uint32_t { PP_NODE = 0, PP_LEAF = 1, PP_FIN = 2, PP_FREE = 3 };
 
@@ -38,39 +43,86 @@ enum : uint32_t { PP_NODE = 0, PP_LEAF = 1, PP_FIN = 2, PP_FREE = 3 };
 enum : uint32_t {
   PW_O = 0, PW_D = 3, PW_INV = 6, PW_SX = 9, PW_SY = 10,                  // the ray as the traversal wants it
   PW_HT = 6, PW_HLEAF = 7, PW_HB0 = 8, PW_HB1 = 9, PW_HB2 = 10,           // ... overwritten by the hit when it retires
-  PW_RNG = 11, PW_COLOR = 15, PW_TP = 18, PW_CNT = 22, PW_PIX = 21, PW_WORDS = 23
+  PW_RNG = 11, PW_COLOR = 15, PW_TP = 18, PW_CNT = 21, PW_WORDS = 22
 };
 // scratch words of a slot (global memory, [word][slot of the whole grid])
-enum : uint32_t { PG_RGB = 0, PG_NRM = 3, PG_LEAF = 6, PG_WORDS = 7 };
+enum : uint32_t { PG_PIX = 0, PG_ROW = 1, PG_COL = 2, PG_RGB = 3, PG_NRM = 6, PG_LEAF = 9, PG_WORDS = 10 };
 // PW_CNT: sample 0..18 | bounce 19..26 | flags 27..28 | kz 29..30 | exactSlab 31
 constexpr uint32_t kPoolMaxSamples = (1u << 19) - 1u, kPoolMaxBounces = 255u;
-constexpr int kPoolQueueCap = 128;
+enum : uint32_t { RING_READY = 0, RING_SHADE = 1, RING_GEN = 2, RING_FETCH = 3 };
+constexpr uint32_t kRingEmpty = 0xFFFFu;
 
-template <bool STATS, int P, int WAVES_PER_SIMD>
-__global__ void __launch_bounds__(256, WAVES_PER_SIMD) path_trace_pool_kernel(DeviceScene sc, mi_trace_result* rays, uint32_t n, uint32_t* workCounter, PoolTune tune,
-                                                                              uint32_t tileStreamW, WaveExtras ex, uint32_t* scratch, uint32_t scratchStride) {
-  static_assert(P >= 64 && P <= kPoolQueueCap, "pool size");
-  constexpr uint32_t QM = kPoolQueueCap - 1;
+// LDS of a workgroup: [PW_WORDS][PWG] u32 | 4 rings x RCAP u16 | ring heads and tails | flags | sin table
+__host__ __device__ constexpr uint32_t pool_ring_cap(uint32_t pwg) { return pwg <= 512u ? 512u : (pwg <= 1024u ? 1024u : 2048u); }
+__host__ __device__ constexpr size_t pool_lds_bytes(uint32_t pwg) { return (size_t)PW_WORDS * pwg * 4u + 4u * pool_ring_cap(pwg) * 2u + 16u * 4u; }
+
+template <bool STATS, int WAVES, int PWG, int WAVES_PER_SIMD>
+__global__ void __launch_bounds__(64 * WAVES, WAVES_PER_SIMD) path_trace_pool_kernel(DeviceScene sc, mi_trace_result* rays, uint32_t n, uint32_t* workCounter, PoolTune tune,
+                                                                                    uint32_t tileStreamW, WaveExtras ex, uint32_t* scratch, uint32_t scratchStride) {
+  static_assert(PWG >= 64 * WAVES && PWG <= 2048, "pool size");
+  constexpr uint32_t RCAP = pool_ring_cap(PWG), RM = RCAP - 1;
   __shared__ float sinTbl[92];
-  __shared__ uint32_t poolLds[4][PW_WORDS * P];
-  __shared__ uint8_t ringLds[4][4][kPoolQueueCap];
-  load_sin_table(sinTbl);
+  extern __shared__ __attribute__((aligned(16))) unsigned char dynLds[];
+  uint32_t* const wp = reinterpret_cast<uint32_t*>(dynLds);
+  volatile uint16_t* const ringEnt = reinterpret_cast<volatile uint16_t*>(dynLds + (size_t)PW_WORDS * PWG * 4u);          // [4][RCAP]
+  uint32_t* const ctl = reinterpret_cast<uint32_t*>(dynLds + (size_t)PW_WORDS * PWG * 4u + 4u * RCAP * 2u);               // head[4], tail[4], drained
+  volatile uint32_t* const vctl = ctl;
+  {
+    for (uint32_t i = threadIdx.x; i < 4u * RCAP; i += blockDim.x) ringEnt[i] = (uint16_t)((i >= RING_FETCH * RCAP && i < RING_FETCH * RCAP + (uint32_t)PWG) ? (i - RING_FETCH * RCAP) : kRingEmpty);
+    if (threadIdx.x < 16u) ctl[threadIdx.x] = (threadIdx.x == 4u + RING_FETCH) ? (uint32_t)PWG : 0u;      // every slot starts on the FETCH ring
+  }
+  load_sin_table(sinTbl);            // (ends with __syncthreads)
 
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t* const wp = poolLds[wave];
-  uint8_t* const qReady = ringLds[wave][0]; uint8_t* const qShade = ringLds[wave][1];
-  uint8_t* const qGen = ringLds[wave][2]; uint8_t* const qFetch = ringLds[wave][3];
-  const uint32_t gslotBase = (blockIdx.x * 4u + wave) * (uint32_t)P;
-  auto SU = [&](uint32_t w, uint32_t s) -> uint32_t& { return wp[w * (uint32_t)P + s]; };
-  auto SF = [&](uint32_t w, uint32_t s) -> float& { return reinterpret_cast<float*>(wp)[w * (uint32_t)P + s]; };
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t gslotBase = blockIdx.x * (uint32_t)PWG;
+  auto SU = [&](uint32_t w, uint32_t s) -> uint32_t& { return wp[w * (uint32_t)PWG + s]; };
+  auto SF = [&](uint32_t w, uint32_t s) -> float& { return reinterpret_cast<float*>(wp)[w * (uint32_t)PWG + s]; };
   auto GU = [&](uint32_t w, uint32_t s) -> uint32_t& { return scratch[(size_t)w * scratchStride + gslotBase + s]; };
   auto GF = [&](uint32_t w, uint32_t s) -> float& { return reinterpret_cast<float*>(scratch)[(size_t)w * scratchStride + gslotBase + s]; };
-  // everything a turn wrote for later turns (other lanes of this wave will read it) has landed
-  auto turnFence = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); };
   auto lanesBelow = [&](unsigned long long m) -> uint32_t { return (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); };
+  auto uni = [&](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+
+  // ---- rings ----
+  // number of entries on a ring as this wave sees it now (reserved entries included)
+  auto ringCount = [&](uint32_t r) -> uint32_t { return vctl[4 + r] - vctl[r]; };
+  // push the slots of the lanes with p: everything the slot needs (LDS words, scratch) was written before
+  auto ringPush = [&](uint32_t r, bool p, uint32_t s) {
+    const unsigned long long m = __ballot(p);
+    if (m == 0ull) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    uint32_t base = 0;
+    if (lane == (uint32_t)__ffsll((long long)m) - 1u) base = atomicAdd(&ctl[4 + r], (uint32_t)__popcll(m));
+    base = uni(__shfl(base, (int)((uint32_t)__ffsll((long long)m) - 1u)));
+    if (p) {
+      volatile uint16_t* e = ringEnt + r * RCAP + ((base + lanesBelow(m)) & RM);
+      while (*e != kRingEmpty) {}                  // (the entry's previous occupant has been claimed but not read yet: never seen in practice)
+      *e = (uint16_t)s;
+    }
+  };
+  // claim up to kmax entries; lanes [0, k) then read entry (base + lane)
+  auto ringClaim = [&](uint32_t r, uint32_t kmax, uint32_t& base) -> uint32_t {
+    uint32_t k = 0, h = 0;
+    if (lane == 0) {
+      for (;;) {
+        h = vctl[r];
+        k = min(vctl[4 + r] - h, kmax);
+        if (k == 0 || atomicCAS(&ctl[r], h, h + k) == h) break;
+      }
+    }
+    base = uni(h);
+    return uni(k);
+  };
+  auto ringTake = [&](uint32_t r, uint32_t idx) -> uint32_t {
+    volatile uint16_t* e = ringEnt + r * RCAP + (idx & RM);
+    uint32_t s;
+    do { s = *e; } while (s == kRingEmpty);        // reserved by a pushing wave, not written yet
+    *e = (uint16_t)kRingEmpty;
+    return s;
+  };
+  auto acquire = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); };
 
   const uint32_t fetchChunk = ex.fetchChunk ? ex.fetchChunk : 64u;
-  uint32_t chunkNext = 0, chunkEnd = 0;
+  uint32_t chunkNext = 0, chunkEnd = 0;            // this wave's share of the work counter
   const uint32_t tiledCount = tileStreamW ? (n / (8u * tileStreamW)) * (8u * tileStreamW) : 0u;
   const uint32_t numNodes = sc.numNodes;
   const uint32_t spp = ex.sampleCount ? ex.sampleCount : sc.samplesPerPixel;
@@ -78,16 +130,6 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) path_trace_pool_kernel(De
   const uint32_t segShift = segment_shift(sc.samplesPerPixel), segMask = (1u << segShift) - 1u;
   const uint32_t segs = segd ? ex.segments : 1u;
   const uint32_t items = n * segs;
-
-  // ---- rings (wave-uniform heads and counts) ----
-  uint32_t hR = 0, nR = 0, hS = 0, nS = 0, hG = 0, nG = 0, hF = 0, nF = (uint32_t)P;
-  for (uint32_t i = lane; i < (uint32_t)P; i += 64u) qFetch[i] = (uint8_t)i;
-  bool drained = false;                            // wave-uniform: the work counter has passed the end of the launch
-  auto push = [&](uint8_t* q, uint32_t& head, uint32_t& count, bool p, uint32_t s) {
-    const unsigned long long m = __ballot(p);
-    if (p) q[(head + count + lanesBelow(m)) & QM] = (uint8_t)s;
-    count += (uint32_t)__popcll(m);
-  };
 
   // ---- the lane's own traversal (its ray stays in registers across SHADE / GEN / FETCH turns) ----
   uint32_t ph = PP_FREE, slot = 0, node = 0, pendLeaf = 0;
@@ -102,19 +144,22 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) path_trace_pool_kernel(De
   unsigned long long tTrav = 0, tShade = 0, tGen = 0, tLoop0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
 
   for (;;) {
+    bool drained = vctl[8] != 0u;                  // some wave has seen the work counter pass the end of the launch
     // ---------------- FETCH: slots whose work unit is finished take the next (pixel, segment) unit ----------------
-    while (nF > 0 && !drained) {
+    while (!drained && ringCount(RING_FETCH) > 0) {
       if (chunkNext >= chunkEnd) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(workCounter, fetchChunk);
-        chunkNext = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        chunkNext = uni(base);
         chunkEnd = chunkNext + fetchChunk;
       }
-      const uint32_t take = min(min(nF, 64u), chunkEnd - chunkNext);
+      uint32_t fbase;
+      const uint32_t take = ringClaim(RING_FETCH, min(64u, chunkEnd - chunkNext), fbase);
+      if (take == 0) break;
       const bool mine = lane < take;
-      const uint32_t fs = mine ? (uint32_t)qFetch[(hF + lane) & QM] : 0u;
+      const uint32_t fs = mine ? ringTake(RING_FETCH, fbase + lane) : 0u;
       const uint32_t idx = chunkNext + lane;
-      hF = (hF + take) & QM; nF -= take; chunkNext += take;
+      chunkNext += take;
       const bool live = mine && idx < items;
       if (live) {
         // (the 8x8 tile walk of trace_wavefront.hpp: a bijection on [0, n), any order gives the same image)
@@ -127,7 +172,7 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) path_trace_pool_kernel(De
         }
         const mi_trace_result* res = rays + entry;
         const float prow = res->u, pcol = res->v;
-        SU(PW_PIX, fs) = entry;
+        GU(PG_PIX, fs) = entry; GF(PG_ROW, fs) = prow; GF(PG_COL, fs) = pcol;
         if (seg == 0) { GF(PG_RGB, fs) = res->rgb.x; GF(PG_RGB + 1, fs) = res->rgb.y; GF(PG_RGB + 2, fs) = res->rgb.z; }
         else { GF(PG_RGB, fs) = 0.f; GF(PG_RGB + 1, fs) = 0.f; GF(PG_RGB + 2, fs) = 0.f; }
         Rng rng;
@@ -136,24 +181,27 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) path_trace_pool_kernel(De
         SU(PW_RNG + 2, fs) = (uint32_t)rng.s1; SU(PW_RNG + 3, fs) = (uint32_t)(rng.s1 >> 32);
         SU(PW_CNT, fs) = (ex.slotColor ? seg - ex.segBase : seg) << segShift;       // sample index; bounce, flags = 0
       }
-      push(qGen, hG, nG, live, fs);
-      if (__ballot(mine && !live)) { drained = true; nF = 0; }          // indices past the end: the launch has no more work
-      turnFence();
+      ringPush(RING_GEN, live, fs);
+      if (__ballot(mine && !live)) { drained = true; if (lane == 0) vctl[8] = 1u; }     // indices past the end: no more work (the dead slots are dropped)
     }
 
     // ---------------- what is there to do ----------------
     uint32_t cN = (uint32_t)__popcll(__ballot(ph == PP_NODE)), cL = (uint32_t)__popcll(__ballot(ph == PP_LEAF));
     const uint32_t cT = cN + cL;
-    if ((cT | nR | nS | nG | nF) == 0) break;
+    const uint32_t nR = ringCount(RING_READY), nS = ringCount(RING_SHADE), nG = ringCount(RING_GEN);
+    if ((cT | nR | nS | nG) == 0 && drained) break;       // nothing queued, nothing to fetch: the other waves finish what their lanes hold
 
     // ---------------- REFILL: free lanes take rays from the READY ring ----------------
     {
-      const uint32_t canFill = min(nR, 64u - cT);
-      if (canFill > 0 && (canFill >= tune.refillMin || cT == 0 || (nS | nG) == 0)) {
+      const uint32_t want = min(nR, 64u - cT);
+      if (want > 0 && (want >= tune.refillMin || cT == 0 || (nS | nG) == 0)) {
+        uint32_t rbase;
+        const uint32_t got = ringClaim(RING_READY, want, rbase);
         const unsigned long long mF = __ballot(ph == PP_FREE);
         const uint32_t rank = lanesBelow(mF);
-        if (ph == PP_FREE && rank < canFill) {
-          const uint32_t s = (uint32_t)qReady[(hR + rank) & QM];
+        if (ph == PP_FREE && rank < got) {
+          const uint32_t s = ringTake(RING_READY, rbase + rank);
+          acquire();
           slot = s;
           o = mk(SF(PW_O, s), SF(PW_O + 1, s), SF(PW_O + 2, s));
           inv = mk(SF(PW_INV, s), SF(PW_INV + 1, s), SF(PW_INV + 2, s));
@@ -166,18 +214,18 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) path_trace_pool_kernel(De
           node = 0;
           ph = (numNodes > 0) ? PP_NODE : PP_FIN;
         }
-        hR = (hR + canFill) & QM; nR -= canFill;
-        continue;
+        if (got > 0) continue;
       }
     }
 
     // ---------------- vote: walk, or serve a ring ----------------
-    uint32_t run;          // 0 = TRAVERSE, 2 = SHADE, 3 = GEN
+    uint32_t run;          // 0 = TRAVERSE, 2 = SHADE, 3 = GEN, 4 = nothing to do right now (another wave holds the work)
     {
       const uint32_t wT = cT * 4u, wS = min(nS, 64u) * tune.shadeW, wG = min(nG, 64u) * tune.genW;
       if (cT > 0 && wT >= max(wS, wG)) run = 0;
-      else run = (nS > 0 && wS >= wG) ? 2 : (nG > 0 ? 3 : (nS > 0 ? 2 : 0));
+      else run = (nS > 0 && wS >= wG) ? 2 : (nG > 0 ? 3 : (nS > 0 ? 2 : (cT > 0 ? 0 : 4)));
     }
+    if (run == 4) { __builtin_amdgcn_s_sleep(8); continue; }
 
     if (run == 0) {
       // ---------------- TRAVERSE: NODE and LEAF steps under a two-way mini-vote (trace_wavefront.hpp) ----------------
@@ -277,18 +325,19 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) path_trace_pool_kernel(De
           SF(PW_HB0, slot) = hit.b0; SF(PW_HB1, slot) = hit.b1; SF(PW_HB2, slot) = hit.b2;
           ph = PP_FREE;
         }
-        push(qShade, hS, nS, fin, slot);
+        ringPush(RING_SHADE, fin, slot);
       }
-      turnFence();
       if (STATS) tTrav += __builtin_amdgcn_s_memtime() - tq0;
     } else if (run == 2) {
       // ---------------- SHADE: up to 64 finished traversals (codelets/TraceCodelets.cpp:214-257) ----------------
       const unsigned long long tq1 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
-      const uint32_t k = min(nS, 64u);
+      uint32_t sbase;
+      const uint32_t k = ringClaim(RING_SHADE, 64u, sbase);
+      if (k == 0) continue;                        // another wave was faster
       if (STATS) { itS++; lnS += k; }
       const bool mine = lane < k;
-      const uint32_t s = mine ? (uint32_t)qShade[(hS + lane) & QM] : 0u;
-      hS = (hS + k) & QM; nS -= k;
+      const uint32_t s = mine ? ringTake(RING_SHADE, sbase + lane) : 0u;
+      acquire();
       bool toReady = false, toGen = false, toFetch = false;
       bool envRay = false;
       uint32_t envSlot = 0;
@@ -302,11 +351,14 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) path_trace_pool_kernel(De
         f3 color = mk(SF(PW_COLOR, s), SF(PW_COLOR + 1, s), SF(PW_COLOR + 2, s));
         f3 tp = mk(SF(PW_TP, s), SF(PW_TP + 1, s), SF(PW_TP + 2, s));
         const uint32_t cnt = SU(PW_CNT, s);
+        // the unit's running rgb sum and pixel are only used when the path ends; asked for now, they arrive meanwhile
+        const f3 rgbIn = mk(GF(PG_RGB, s), GF(PG_RGB + 1, s), GF(PG_RGB + 2, s));
+        const uint32_t pixNow = GU(PG_PIX, s);
         uint32_t sample = cnt & kPoolMaxSamples, bounce = (cnt >> 19) & 0xFFu, oFlags = (cnt >> 27) & 3u;
         const bool lastSample = sample + 1u >= spp;          // this path's final state is the pixel's AOV record
         f3 nrm = mk(0.f, 0.f, 1.f);                          // HitRecord ctor, geometry.hpp:236-242
         uint32_t lastLeaf = 0xFFFFFFFFu;
-        bool terminated = false;
+        bool terminated = false, rgbNaN = false;
         const bool gotHit = h2.leaf != 0xFFFFFFFFu;
         if (gotHit) {
           const GLeaf L = sc.leaves[h2.leaf];
@@ -332,8 +384,7 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) path_trace_pool_kernel(De
             sd = nd2;
             if (refracted) tp = tp * albedo;
           } else {
-            const float qn = __builtin_nanf("");
-            GF(PG_RGB, s) = GF(PG_RGB, s) * qn; GF(PG_RGB + 1, s) = GF(PG_RGB + 1, s) * qn; GF(PG_RGB + 2, s) = GF(PG_RGB + 2, s) * qn;
+            rgbNaN = true;                                   // rgb *= NaN (codelets :240-244)
             oFlags |= MI_FLAG_ERROR;
           }
         } else {
@@ -344,6 +395,8 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) path_trace_pool_kernel(De
             lastLeaf = GU(PG_LEAF, s);
           }
         }
+        f3 sum = rgbIn;
+        if (rgbNaN) { const float qn = __builtin_nanf(""); sum = mk(sum.x * qn, sum.y * qn, sum.z * qn); }
         if (!terminated && bounce > sc.rouletteStartDepth) {
           const float u1 = rng_uniform01(rng);
           if (roulette_stop(u1, tp)) terminated = true;
@@ -351,9 +404,7 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) path_trace_pool_kernel(De
         bounce++;
         if (bounce >= sc.maxPathLength) terminated = true;
         if (terminated) {
-          const uint32_t pixNow = SU(PW_PIX, s);
           mi_trace_result* res = rays + pixNow;
-          f3 sum = mk(0, 0, 0);
           if (ex.slotColor) {
             const size_t q = (size_t)sample * n + pixNow;
             ex.slotColor[3 * q] = color.x; ex.slotColor[3 * q + 1] = color.y; ex.slotColor[3 * q + 2] = color.z;
@@ -362,7 +413,7 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) path_trace_pool_kernel(De
             envDir = sd; envTp = tp;
             if (!envRay) ex.u[q] = -1.f;
           } else {
-            sum = mk(GF(PG_RGB, s) + color.x, GF(PG_RGB + 1, s) + color.y, GF(PG_RGB + 2, s) + color.z);
+            sum = mk(sum.x + color.x, sum.y + color.y, sum.z + color.z);
           }
           ++paths;
           ++sample;
@@ -400,6 +451,7 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) path_trace_pool_kernel(De
           }
         } else {
           // next bounce: offsetRay + cast set-up (codelets :207-211)
+          if (rgbNaN) { GF(PG_RGB, s) = sum.x; GF(PG_RGB + 1, s) = sum.y; GF(PG_RGB + 2, s) = sum.z; }
           if (lastSample) { GF(PG_NRM, s) = nrm.x; GF(PG_NRM + 1, s) = nrm.y; GF(PG_NRM + 2, s) = nrm.z; GU(PG_LEAF, s) = lastLeaf; }
           so = offset_origin(so, sd, nrm);
           const f3 si = mk(1.f / sd.x, 1.f / sd.y, 1.f / sd.z);
@@ -441,25 +493,25 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) path_trace_pool_kernel(De
           }
         }
       }
-      push(qReady, hR, nR, toReady, s);
-      push(qGen, hG, nG, toGen, s);
-      if (!drained) push(qFetch, hF, nF, toFetch, s);      // (after the end of the launch a finished slot simply dies)
-      turnFence();
+      ringPush(RING_READY, toReady, s);
+      ringPush(RING_GEN, toGen, s);
+      if (vctl[8] == 0u) ringPush(RING_FETCH, toFetch, s);      // (after the end of the launch a finished slot simply dies)
       if (STATS) tShade += __builtin_amdgcn_s_memtime() - tq1;
     } else {
       // ---------------- GEN: camera rays of up to 64 next samples (codelets/TraceCodelets.cpp:142-164) ----------------
       const unsigned long long tq2 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
-      const uint32_t k = min(nG, 64u);
+      uint32_t gbase;
+      const uint32_t k = ringClaim(RING_GEN, 64u, gbase);
+      if (k == 0) continue;
       if (STATS) { itG++; lnG += k; }
       const bool mine = lane < k;
-      const uint32_t s = mine ? (uint32_t)qGen[(hG + lane) & QM] : 0u;
-      hG = (hG + k) & QM; nG -= k;
+      const uint32_t s = mine ? ringTake(RING_GEN, gbase + lane) : 0u;
+      acquire();
       if (mine) {
         Rng rng;
         rng.s0 = (uint64_t)SU(PW_RNG, s) | ((uint64_t)SU(PW_RNG + 1, s) << 32); rng.s1 = (uint64_t)SU(PW_RNG + 2, s) | ((uint64_t)SU(PW_RNG + 3, s) << 32);
         const uint32_t sample = SU(PW_CNT, s) & kPoolMaxSamples;
-        const mi_trace_result* res = rays + SU(PW_PIX, s);
-        const float prow = res->u, pcol = res->v;
+        const float prow = GF(PG_ROW, s), pcol = GF(PG_COL, s);
         float g0, g1;
         rng_gauss2(rng, sinTbl, g0, g1);
         const float jr = prow + sc.antiAliasScale * g0, jc = pcol + sc.antiAliasScale * g1;
@@ -479,8 +531,7 @@ __global__ void __launch_bounds__(256, WAVES_PER_SIMD) path_trace_pool_kernel(De
         SU(PW_CNT, s) = sample | (s2.kz << 29) | (ex2 ? 0x80000000u : 0u);             // bounce 0, flags 0
         ++casts;
       }
-      push(qReady, hR, nR, mine, s);
-      turnFence();
+      ringPush(RING_READY, mine, s);
       if (STATS) tGen += __builtin_amdgcn_s_memtime() - tq2;
     }
   }

@@ -81,20 +81,20 @@ def test_traversal_visits_exactly_the_reference_nodes(scenes):
 # path trace: rgb sums + last-sample hit records, per-pixel RNG streams
 # ------------------------------------------------------------------------------------------------------
 def _with_kernel(dev, kernel):
-    """kernel strings: "0" | "1" | "1w4" | "2" | "3" | "3p96" | "3p128" (variant + waves / pool size)"""
+    """kernel strings: "0" | "1" | "1w4" | "2" | "3" | "3p8" | "3p16" (variant + waves per SIMD / waves per pool workgroup)"""
     dev.set_option("kernel", kernel[0])
     if kernel.endswith("w4"):
         dev.set_option("waves", 4)
     if "p" in kernel:
-        dev.set_option("pool_slots", kernel.split("p")[1])
+        dev.set_option("pool_waves", kernel.split("p")[1])
     return dev
 
 
-@pytest.mark.parametrize("kernel", ["0", "1", "1w4", "2", "3", "3p96", "3p128"])
+@pytest.mark.parametrize("kernel", ["0", "1", "1w4", "2", "3", "3p8", "3p16"])
 @pytest.mark.parametrize("name,size,spp", [("box-simple", 128, 32), ("box", 160, 24), ("spheres", 128, 32)])
 def test_path_trace_bit_exact(scenes, name, size, spp, kernel):
     """kernel 0 = nested-loop kernel, 1 = phase-scheduled persistent kernel, 2 = the same with the BVH
-    prefix staged in LDS, 3 = the path-pool kernel (104, 96 or 128 slots per wave); 1 is built for 5 waves per SIMD
+    prefix staged in LDS, 3 = the path-pool kernel (workgroups of 4, 8 or 16 waves); 1 is built for 5 waves per SIMD
     and for 4 ("1w4"). All of them must reproduce the oracle bit for bit."""
     s = scenes[name]
     s.desc.set_image(size, size)
@@ -616,7 +616,7 @@ def test_randomised_render_parameters_against_oracle(scenes):
         d.set_image(96, 64); d.anti_alias_scale = 0.25; d.max_path_length = 10; d.roulette_start_depth = 3; d.rng_seed = 1442
 
 
-@pytest.mark.parametrize("kernel,spp", [("0", 300), ("1", 300), ("2", 300), ("3", 300), ("0", 700), ("1", 700), ("2", 700), ("3", 700), ("3p128", 700)])
+@pytest.mark.parametrize("kernel,spp", [("0", 300), ("1", 300), ("2", 300), ("3", 300), ("0", 700), ("1", 700), ("2", 700), ("3", 700), ("3p16", 700)])
 def test_segmented_pixels_bit_exact(scenes, kernel, spp):
     """More samples per pixel than one segment holds: the pixel is traced as segments (about sixteen per pixel, 4 to 64
     samples long), each with its own RNG stream and partial rgb sum, added in segment order.

@@ -1,6 +1,6 @@
 """Lane occupancy of the persistent kernel's turns (instrumented build, MI_RAYLIB_FULL_STATS=1).
 
-    python tools/phase_probe.py [scene] [edge] [spp]
+    python tools/phase_probe.py [scene] [edge] [spp] [option=value:option=value...]
 
 Prints, per phase, the number of wave turns, the lanes that were in that phase when the turn ran, the mean
 occupancy (lanes / 64 turns) and the share of the kernel's cycle counters spent in traversal / shading / ray
@@ -9,7 +9,6 @@ generation. The instrumented build is the 4-waves-per-SIMD kernel with rolled NO
 import os
 import sys
 
-os.environ["MI_RAYLIB_FULL_STATS"] = "1"
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import ipu_ray_lib_amd as irl  # noqa: E402
 
@@ -22,7 +21,11 @@ def main():
     s.desc.set_image(edge, edge)
     s.desc.path_trace = 1
     s.desc.samples_per_pixel = spp
-    dev = irl.IpuScene(s.desc)
+    dev = irl.IpuScene(s.desc).set_option("full_stats", 1)
+    if len(sys.argv) > 4:
+        for kv in sys.argv[4].split(":"):
+            k, v = kv.split("=", 1)
+            dev.set_option(k, v)
     rays = s.init_ray_stream()
     dev.run(rays, irl.MODE_PATH_TRACE)
     c, p = dev.counters(), dev.phase_stats()
@@ -30,7 +33,7 @@ def main():
           f"{c['leaf_tests'] / c['casts']:.2f} primitive tests per cast, {c['casts'] / c['paths']:.2f} casts per path")
     for k in ("node", "leaf", "shade", "gen"):
         it, ln = p[k]["iters"], p[k]["lanes"]
-        print(f"  {k:5s} turns {it:12d}  lanes {ln:14d}  occupancy {ln / (64.0 * it) if it else 0.0:6.3f}")
+        print(f"  {k:5s} turns {it:12d}  lanes {ln:14d}  occupancy {ln / (64.0 * it) if it else 0.0:6.3f}  turns per 64 casts {64.0 * it / c['casts']:7.2f}")
     cy = p["cycles"]
     tot = float(cy["total"]) or 1.0
     print("  cycles: traverse %.3f  shade %.3f  gen %.3f" % (cy["traverse"] / tot, cy["shade"] / tot, cy["gen"] / tot))
