@@ -174,6 +174,9 @@ int mi_reset_counters(mi_scene* scene);
  * stats[8..11] = shader cycles summed over waves spent in {traversal loop, SHADE, GEN, whole kernel loop}.
  * No reference counterpart (the IPU has no SIMT lanes); used by DESIGN.md's occupancy table. */
 int mi_get_phase_stats(mi_scene* scene, uint64_t stats[12]);
+/* Scheduler bookkeeping of the path-pool kernel (kernel 3, instrumented build only): {loop iterations, refill turns,
+ * lanes refilled, idle iterations, lost ring claims, traversal bursts, lanes walking at burst start, cycles in refill}. */
+int mi_get_pool_stats(mi_scene* scene, uint64_t stats[8]);
 
 /* Replaces: IpuScene::loadNifModel (src/IpuScene.cpp:174-187) with the weights handed over as
  * arrays (the file side — nif_metadata.txt + Keras-H5 — is mi_host_nif_load in mi_scene_host.h).

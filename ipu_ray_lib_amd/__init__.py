@@ -173,6 +173,7 @@ def device_lib() -> C.CDLL:
         lib.mi_scene_set_max_nif_batch.argtypes = [C.c_void_p, C.c_size_t]
         lib.mi_scene_set_ray_batch.argtypes = [C.c_void_p, C.c_size_t]
         lib.mi_nif_infer_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.mi_get_pool_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         lib.mi_scene_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         _device = lib
     return _device
@@ -433,6 +434,11 @@ class IpuScene:
         out = {n: {"iters": c[2 * i], "lanes": c[2 * i + 1]} for i, n in enumerate(names)}
         out["cycles"] = {"traverse": c[8], "shade": c[9], "gen": c[10], "total": c[11]}
         return out
+
+    def pool_stats(self) -> dict:
+        c = (C.c_uint64 * 8)()
+        _check_dev(self._lib.mi_get_pool_stats(self._h, c))
+        return dict(zip(("loops", "refill_turns", "refill_lanes", "idle", "lost_claims", "bursts", "burst_lanes", "refill_cycles"), [int(x) for x in c]))
 
     def reset_counters(self):
         _check_dev(self._lib.mi_reset_counters(self._h))

@@ -302,9 +302,9 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
   ds.maxPathLength = d.max_path_length; ds.rouletteStartDepth = d.roulette_start_depth;
   ds.samplesPerPixel = d.samples_per_pixel;
   ds.rngSeed = d.rng_seed;
-  HIP_CHECK(hipMalloc(&S.d_counters, 16 * sizeof(unsigned long long)));
+  HIP_CHECK(hipMalloc(&S.d_counters, 32 * sizeof(unsigned long long)));
   S.keep(S.d_counters);
-  HIP_CHECK(hipMemset(S.d_counters, 0, 16 * sizeof(unsigned long long)));
+  HIP_CHECK(hipMemset(S.d_counters, 0, 32 * sizeof(unsigned long long)));
   ds.counters = S.d_counters;
 }
 
@@ -662,12 +662,23 @@ int mi_get_phase_stats(mi_scene* scene, uint64_t stats[12]) {
   });
 }
 
+int mi_get_pool_stats(mi_scene* scene, uint64_t stats[8]) {
+  if (!scene || !stats) { g_err = "mi_get_pool_stats: null argument"; return MI_ERR_INVALID_ARG; }
+  return guarded([&] {
+    HIP_CHECK(hipSetDevice(scene->device));
+    HIP_CHECK(hipDeviceSynchronize());
+    unsigned long long h[32];
+    HIP_CHECK(hipMemcpy(h, scene->d_counters, sizeof h, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; ++i) stats[i] = h[16 + i];
+  });
+}
+
 int mi_reset_counters(mi_scene* scene) {
   if (!scene) { g_err = "mi_reset_counters: null argument"; return MI_ERR_INVALID_ARG; }
   return guarded([&] {
     HIP_CHECK(hipSetDevice(scene->device));
     HIP_CHECK(hipDeviceSynchronize());
-    HIP_CHECK(hipMemset(scene->d_counters, 0, 16 * sizeof(unsigned long long)));
+    HIP_CHECK(hipMemset(scene->d_counters, 0, 32 * sizeof(unsigned long long)));
   });
 }
 

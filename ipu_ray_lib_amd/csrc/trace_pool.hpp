@@ -121,8 +121,6 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES_PER_SIMD) path_trace_pool_ke
   };
   auto acquire = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); };
 
-  const uint32_t fetchChunk = ex.fetchChunk ? ex.fetchChunk : 64u;
-  uint32_t chunkNext = 0, chunkEnd = 0;            // this wave's share of the work counter
   const uint32_t tiledCount = tileStreamW ? (n / (8u * tileStreamW)) * (8u * tileStreamW) : 0u;
   const uint32_t numNodes = sc.numNodes;
   const uint32_t spp = ex.sampleCount ? ex.sampleCount : sc.samplesPerPixel;
@@ -142,24 +140,24 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES_PER_SIMD) path_trace_pool_ke
   uint32_t casts = 0, paths = 0;
   uint32_t itN = 0, itL = 0, itS = 0, itG = 0, lnN = 0, lnL = 0, lnS = 0, lnG = 0;
   unsigned long long tTrav = 0, tShade = 0, tGen = 0, tLoop0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+  uint32_t itLoop = 0, itRefill = 0, lnRefill = 0, itIdle = 0, itFail = 0, itBurst = 0, lnBurst = 0;      // STATS: scheduler bookkeeping
+  unsigned long long tRefill = 0;
 
   for (;;) {
+    if (STATS) itLoop++;
     bool drained = vctl[8] != 0u;                  // some wave has seen the work counter pass the end of the launch
     // ---------------- FETCH: slots whose work unit is finished take the next (pixel, segment) unit ----------------
     while (!drained && ringCount(RING_FETCH) > 0) {
-      if (chunkNext >= chunkEnd) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(workCounter, fetchChunk);
-        chunkNext = uni(base);
-        chunkEnd = chunkNext + fetchChunk;
-      }
+      // One global atomic per turn hands out exactly as many work indices as slots were claimed, so no wave ever
+      // holds indices it might not use; the first index past the end tells every wave to stop fetching.
       uint32_t fbase;
-      const uint32_t take = ringClaim(RING_FETCH, min(64u, chunkEnd - chunkNext), fbase);
+      const uint32_t take = ringClaim(RING_FETCH, 64u, fbase);
       if (take == 0) break;
       const bool mine = lane < take;
       const uint32_t fs = mine ? ringTake(RING_FETCH, fbase + lane) : 0u;
-      const uint32_t idx = chunkNext + lane;
-      chunkNext += take;
+      uint32_t ibase = 0;
+      if (lane == 0) ibase = atomicAdd(workCounter, take);
+      const uint32_t idx = uni(ibase) + lane;
       const bool live = mine && idx < items;
       if (live) {
         // (the 8x8 tile walk of trace_wavefront.hpp: a bijection on [0, n), any order gives the same image)
@@ -195,8 +193,10 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES_PER_SIMD) path_trace_pool_ke
     {
       const uint32_t want = min(nR, 64u - cT);
       if (want > 0 && (want >= tune.refillMin || cT == 0 || (nS | nG) == 0)) {
+        const unsigned long long tqr = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
         uint32_t rbase;
         const uint32_t got = ringClaim(RING_READY, want, rbase);
+        if (STATS) { itRefill++; lnRefill += got; }
         const unsigned long long mF = __ballot(ph == PP_FREE);
         const uint32_t rank = lanesBelow(mF);
         if (ph == PP_FREE && rank < got) {
@@ -214,6 +214,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES_PER_SIMD) path_trace_pool_ke
           node = 0;
           ph = (numNodes > 0) ? PP_NODE : PP_FIN;
         }
+        if (STATS) tRefill += __builtin_amdgcn_s_memtime() - tqr;
         if (got > 0) continue;
       }
     }
@@ -225,12 +226,13 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES_PER_SIMD) path_trace_pool_ke
       if (cT > 0 && wT >= max(wS, wG)) run = 0;
       else run = (nS > 0 && wS >= wG) ? 2 : (nG > 0 ? 3 : (nS > 0 ? 2 : (cT > 0 ? 0 : 4)));
     }
-    if (run == 4) { __builtin_amdgcn_s_sleep(8); continue; }
+    if (run == 4) { if (STATS) itIdle++; __builtin_amdgcn_s_sleep(8); continue; }
 
     if (run == 0) {
       // ---------------- TRAVERSE: NODE and LEAF steps under a two-way mini-vote (trace_wavefront.hpp) ----------------
       const unsigned long long tq0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
       if (tune.prio == 1) __builtin_amdgcn_s_setprio(1);
+      if (STATS) { itBurst++; lnBurst += cT; }
       uint32_t steps = 0;
       const bool anyExact = __ballot(exactSlab && ph <= PP_LEAF) != 0ull;
       auto nodeBodyT = [&](auto exactTag) -> bool {
@@ -333,7 +335,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES_PER_SIMD) path_trace_pool_ke
       const unsigned long long tq1 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
       uint32_t sbase;
       const uint32_t k = ringClaim(RING_SHADE, 64u, sbase);
-      if (k == 0) continue;                        // another wave was faster
+      if (k == 0) { if (STATS) itFail++; continue; }                        // another wave was faster
       if (STATS) { itS++; lnS += k; }
       const bool mine = lane < k;
       const uint32_t s = mine ? ringTake(RING_SHADE, sbase + lane) : 0u;
@@ -502,7 +504,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES_PER_SIMD) path_trace_pool_ke
       const unsigned long long tq2 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
       uint32_t gbase;
       const uint32_t k = ringClaim(RING_GEN, 64u, gbase);
-      if (k == 0) continue;
+      if (k == 0) { if (STATS) itFail++; continue; }
       if (STATS) { itG++; lnG += k; }
       const bool mine = lane < k;
       const uint32_t s = mine ? ringTake(RING_GEN, gbase + lane) : 0u;
@@ -543,6 +545,10 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES_PER_SIMD) path_trace_pool_ke
     atomicAdd(&sc.counters[10], (unsigned long long)itG); atomicAdd(&sc.counters[11], (unsigned long long)lnG);
     atomicAdd(&sc.counters[12], tTrav); atomicAdd(&sc.counters[13], tShade); atomicAdd(&sc.counters[14], tGen);
     atomicAdd(&sc.counters[15], __builtin_amdgcn_s_memtime() - tLoop0);
+    atomicAdd(&sc.counters[16], (unsigned long long)itLoop); atomicAdd(&sc.counters[17], (unsigned long long)itRefill);
+    atomicAdd(&sc.counters[18], (unsigned long long)lnRefill); atomicAdd(&sc.counters[19], (unsigned long long)itIdle);
+    atomicAdd(&sc.counters[20], (unsigned long long)itFail); atomicAdd(&sc.counters[21], (unsigned long long)itBurst);
+    atomicAdd(&sc.counters[22], (unsigned long long)lnBurst); atomicAdd(&sc.counters[23], tRefill);
   }
 }
 

@@ -37,6 +37,12 @@ def main():
     cy = p["cycles"]
     tot = float(cy["total"]) or 1.0
     print("  cycles: traverse %.3f  shade %.3f  gen %.3f" % (cy["traverse"] / tot, cy["shade"] / tot, cy["gen"] / tot))
+    ps = dev.pool_stats()
+    if ps["loops"]:
+        wc = c["casts"] / 64.0
+        print("  pool: per 64 casts: loops %.2f  refill turns %.2f (%.1f lanes each)  bursts %.2f (%.1f lanes at start)  idle %.2f  lost claims %.3f; refill cycles %.3f" % (
+            ps["loops"] / wc, ps["refill_turns"] / wc, ps["refill_lanes"] / max(ps["refill_turns"], 1), ps["bursts"] / wc,
+            ps["burst_lanes"] / max(ps["bursts"], 1), ps["idle"] / wc, ps["lost_claims"] / wc, ps["refill_cycles"] / tot))
     dev.close()
 
 
