@@ -217,6 +217,34 @@ int mi_scene_set_option(mi_scene* scene, const char* key, const char* value);
 int mi_nif_infer_device(mi_scene* scene, const float* d_u, const float* d_v, float* d_bgr,
                         size_t n, void* hip_stream);
 
+/* ---- several GPUs in one process -------------------------------------------------------
+ * Replaces: the replicas of an IpuScene (RuntimeConfig.numIpus / numReplicas, trace.cpp:297-309; scene replicated per
+ * device src/IpuScene.cpp:473-483; replicas pull disjoint ray batches round-robin from the one stream :676-684; every
+ * batch is written back into the caller's stream :699-732).
+ * mi_group_create builds one mi_scene per entry of `devices` (HIP ordinals; an ordinal may repeat - several replicas
+ * then share that GPU, which is how the path is rehearsed on a one-GPU box). mi_group_render deals the host stream in
+ * bands (8 rows of the render window per band, band b to replica b % R: ipu_ray_lib_amd/csrc/ray_shard.hpp, also
+ * exported as mi_shard_* by libmi_scene_host.so), traces every replica's share on its own HIP stream with no exchange
+ * while the frame renders, moves the finished shares to the first replica's device with ONE RCCL group call
+ * (ncclSend / ncclRecv over xGMI), restores stream order there and overwrites `rays` in place. Every pixel owns its
+ * RNG streams, so the result is bit-identical for any number of replicas.
+ * `transport`: 0 = RCCL as soon as more than one device takes part (peer copies otherwise), 1 = RCCL always, 2 = peer
+ * copies only. RCCL is loaded with dlopen when the first group needs it.
+ * mi_group_scene hands out a replica's scene for the per-scene setters (mi_scene_set_nif, mi_scene_set_option, ...),
+ * which must be applied to every replica alike. The callback is called once per ray batch, in batch order, after the
+ * frame has been assembled. */
+typedef struct mi_group mi_group;
+int mi_group_create(const mi_scene_desc* desc, const int32_t* devices, uint32_t num_replicas, int32_t transport, mi_group** out);
+void mi_group_destroy(mi_group* group);
+uint32_t mi_group_size(const mi_group* group);
+mi_scene* mi_group_scene(mi_group* group, uint32_t replica);
+int mi_group_set_ray_batch(mi_group* group, size_t rays_per_batch);
+int mi_group_render(mi_group* group, int mode, mi_trace_result* rays, size_t n, mi_ray_callback cb, void* user);
+double mi_group_trace_time_secs(const mi_group* group);
+int mi_group_get_counters(mi_group* group, uint64_t counts[4]);       /* summed over the replicas */
+/* What the last mi_group_render moved: info[0] = RCCL send/recv pairs, info[1] = peer copies, info[2] = bands uploaded. */
+int mi_group_last_transfer(const mi_group* group, uint64_t info[3]);
+
 /* Thread-local message for the last failing call on this thread. Never NULL. */
 const char* mi_last_error(void);
 

@@ -76,6 +76,22 @@ int mi_scene_deserialise(const uint8_t* blob, size_t size, mi_scene_desc* desc, 
  * (Serialiser::calculatePadding, Serialiser.hpp:30-39). */
 uint32_t mi_blob_padding(uint32_t base_align, size_t offset, uint32_t align);
 
+/* ---- ray-band sharding -----------------------------------------------------------
+ * How a ray stream is dealt to the R replicas of a multi-GPU render and put together again; replaces the
+ * round-robin batch pull of the reference's replicas (src/IpuScene.cpp:676-684, src/RayCallback.cpp:8-24).
+ * The stream is cut into bands of `band` consecutive rays, band b belongs to replica b % R. One definition
+ * (ipu_ray_lib_amd/csrc/ray_shard.hpp) serves these functions, mi_group_render and the Python ranks of bench.py.
+ *   mi_shard_band_rays     band length for a stream of n rays rendered for a window `window_w` pixels wide: 8 rows
+ *                          of the window when the stream is made of full rows, else 4096 rays
+ *   mi_shard_count         rays replica r renders
+ *   mi_shard_stream_index  out[k] = stream position of the k-th ray of replica r's stream
+ *   mi_shard_frame_index   out[i] = position of stream ray i in the gathered buffer (replica 0's stream, then
+ *                          replica 1's, ...): the de-interleave map the frame is assembled with            */
+size_t mi_shard_band_rays(size_t n, uint32_t window_w);
+size_t mi_shard_count(size_t n, size_t band, uint32_t replicas, uint32_t r);
+int mi_shard_stream_index(size_t n, size_t band, uint32_t replicas, uint32_t r, uint64_t* out, size_t capacity);
+int mi_shard_frame_index(size_t n, size_t band, uint32_t replicas, uint64_t* out);
+
 /* ---- NIF assets ----------------------------------------------------------------
  * IpuScene::loadNifModel(assetPath) (src/IpuScene.cpp:174-187) reads <assetPath>/nif_metadata.txt
  * (NifMetaData.cpp:11-71) and <assetPath>/converted.hdf5, a Keras "Functional" model whose Dense layers

@@ -133,6 +133,12 @@ def host_lib() -> C.CDLL:
         lib.mi_scene_deserialise.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(SceneDesc), C.POINTER(C.c_size_t)]
         lib.mi_blob_padding.argtypes = [C.c_uint32, C.c_size_t, C.c_uint32]
         lib.mi_blob_padding.restype = C.c_uint32
+        lib.mi_shard_band_rays.argtypes = [C.c_size_t, C.c_uint32]
+        lib.mi_shard_band_rays.restype = C.c_size_t
+        lib.mi_shard_count.argtypes = [C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32]
+        lib.mi_shard_count.restype = C.c_size_t
+        lib.mi_shard_stream_index.argtypes = [C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t]
+        lib.mi_shard_frame_index.argtypes = [C.c_size_t, C.c_size_t, C.c_uint32, C.c_void_p]
         lib.mi_host_nif_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
         lib.mi_host_nif_describe.argtypes = [C.c_void_p, C.POINTER(NifDesc)]
         lib.mi_host_nif_destroy.argtypes = [C.c_void_p]
@@ -173,6 +179,19 @@ def device_lib() -> C.CDLL:
         lib.mi_scene_set_max_nif_batch.argtypes = [C.c_void_p, C.c_size_t]
         lib.mi_scene_set_ray_batch.argtypes = [C.c_void_p, C.c_size_t]
         lib.mi_nif_infer_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.mi_group_create.argtypes = [C.POINTER(SceneDesc), C.c_void_p, C.c_uint32, C.c_int32, C.POINTER(C.c_void_p)]
+        lib.mi_group_destroy.argtypes = [C.c_void_p]
+        lib.mi_group_destroy.restype = None
+        lib.mi_group_size.argtypes = [C.c_void_p]
+        lib.mi_group_size.restype = C.c_uint32
+        lib.mi_group_scene.argtypes = [C.c_void_p, C.c_uint32]
+        lib.mi_group_scene.restype = C.c_void_p
+        lib.mi_group_set_ray_batch.argtypes = [C.c_void_p, C.c_size_t]
+        lib.mi_group_render.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        lib.mi_group_trace_time_secs.argtypes = [C.c_void_p]
+        lib.mi_group_trace_time_secs.restype = C.c_double
+        lib.mi_group_get_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        lib.mi_group_last_transfer.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         lib.mi_get_pool_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         lib.mi_scene_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         _device = lib
@@ -446,6 +465,76 @@ class IpuScene:
     def close(self):
         if self._h:
             self._lib.mi_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _BorrowedScene(IpuScene):
+    """A replica's scene handle inside an IpuGroup (owned by the group: never destroyed from here)."""
+
+    def __init__(self, handle, desc):
+        self._lib = device_lib()
+        self._h = C.c_void_p(handle)
+        self.desc = desc
+
+    def close(self):
+        self._h = C.c_void_p()
+
+
+TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_COPY = 0, 1, 2
+
+
+class IpuGroup:
+    """An IpuScene with numReplicas > 1 (RuntimeConfig, trace.cpp:297-309) in ONE process: a scene replica per entry
+    of `devices` (ordinals may repeat), the host ray stream dealt to them in 8-row bands, one RCCL gather to the first
+    replica's device at frame end (mi_group_* in include/mi_raylib.h)."""
+
+    def __init__(self, desc: SceneDesc, devices, transport: int = TRANSPORT_AUTO):
+        self._lib = device_lib()
+        self._h = C.c_void_p()
+        self.desc = desc
+        dv = np.ascontiguousarray(devices, dtype=np.int32)
+        _check_dev(self._lib.mi_group_create(C.byref(desc), dv.ctypes.data, dv.size, int(transport), C.byref(self._h)))
+
+    def scenes(self):
+        return [_BorrowedScene(self._lib.mi_group_scene(self._h, i), self.desc) for i in range(self._lib.mi_group_size(self._h))]
+
+    def setRayBatch(self, rays_per_batch: int):
+        _check_dev(self._lib.mi_group_set_ray_batch(self._h, int(rays_per_batch)))
+
+    def run(self, rays: np.ndarray, mode: int | None = None, callback=None) -> np.ndarray:
+        assert rays.dtype == TRACE_RESULT and rays.flags["C_CONTIGUOUS"]
+        if mode is None:
+            mode = MODE_PATH_TRACE if self.desc.path_trace else MODE_SHADOW_TRACE
+        cb = None
+        if callback is not None:
+            base = rays.ctypes.data
+            proto = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t)
+            cb = proto(lambda user, idx, ptr, cnt: callback(idx, (ptr - base) // TRACE_RESULT.itemsize, cnt))
+        _check_dev(self._lib.mi_group_render(self._h, mode, rays.ctypes.data, rays.size, cb, None))
+        return rays
+
+    def getTraceTimeSecs(self) -> float:
+        return float(self._lib.mi_group_trace_time_secs(self._h))
+
+    def counters(self) -> dict:
+        c = (C.c_uint64 * 4)()
+        _check_dev(self._lib.mi_group_get_counters(self._h, c))
+        return {"casts": c[0], "nodes_visited": c[1], "leaf_tests": c[2], "paths": c[3]}
+
+    def last_transfer(self) -> dict:
+        c = (C.c_uint64 * 3)()
+        _check_dev(self._lib.mi_group_last_transfer(self._h, c))
+        return {"rccl_messages": c[0], "peer_copies": c[1], "bands": c[2]}
+
+    def close(self):
+        if self._h:
+            self._lib.mi_group_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -22,10 +22,11 @@ namespace mi {
 // reference constructor.
 using SceneRef = mi_scene_desc;
 
-struct RuntimeConfig {       // subset of ipu_utils::RuntimeConfig that has a meaning on a GPU node
-  uint32_t numGpus = 1;      // numIpus
-  uint32_t numReplicas = 1;
+struct RuntimeConfig {       // subset of ipu_utils::RuntimeConfig that has a meaning on a GPU node (trace.cpp:297-309)
+  uint32_t numGpus = 1;      // numIpus: devices device .. device + numGpus - 1 take part
+  uint32_t numReplicas = 1;  // scene replicas the ray stream is dealt to (>= numGpus; replica i runs on device + i % numGpus)
   int device = 0;            // first device ordinal
+  int transport = 0;         // mi_group_create: 0 = RCCL when more than one device takes part, 1 = RCCL always, 2 = peer copies
 };
 
 class IpuScene {
@@ -38,7 +39,7 @@ class IpuScene {
     data.spheres = spheres.data(); data.num_spheres = (uint32_t)spheres.size();
     data.discs = discs.data(); data.num_discs = (uint32_t)discs.size();
   }
-  ~IpuScene() { if (scene) mi_scene_destroy(scene); if (nif) mi_host_nif_destroy(nif); }
+  ~IpuScene() { release(); if (nif) mi_host_nif_destroy(nif); }
   IpuScene(const IpuScene&) = delete;
   IpuScene& operator=(const IpuScene&) = delete;
 
@@ -69,34 +70,66 @@ class IpuScene {
   double getTraceTimeSecs() const { return traceTimeSecs; }
   RayCallbackFn* getRayCallback() { return rayFunc; }
 
-  // GraphManager().run(*this): build (scene upload) + execute (trace the ray stream in place).
+  // GraphManager().run(*this): build (scene upload) + execute (trace the ray stream in place). With more than one GPU
+  // or replica the stream is dealt to the replicas in 8-row bands and the frame is assembled on the first device with
+  // one RCCL group call (mi_group_render), as the reference's IpuScene spreads its ray batches over the replicas
+  // (src/IpuScene.cpp:676-684, 699-732).
   int run() {
+    release();
+    const uint32_t gpus = config.numGpus ? config.numGpus : 1u;
+    const uint32_t replicas = config.numReplicas > gpus ? config.numReplicas : gpus;
+    const int mode = data.path_trace ? MI_MODE_PATH_TRACE : MI_MODE_SHADOW_TRACE;
+    // batch = 1440 compute tiles x 6 workers x raysPerWorker rays, as on one IPU (src/IpuScene.cpp:360-361)
+    const size_t batch = rayFunc ? (size_t)1440 * 6 * (maxRaysPerWorker ? maxRaysPerWorker : 1) : 0;
+    if (replicas > 1) {
+      std::vector<int32_t> devices(replicas);
+      for (uint32_t i = 0; i < replicas; ++i) devices[i] = config.device + (int32_t)(i % gpus);
+      if (mi_group_create(&data, devices.data(), replicas, config.transport, &group) != MI_OK) return fail("scene group creation");
+      for (uint32_t i = 0; i < replicas; ++i) if (!configure(mi_group_scene(group, i))) return EXIT_FAILURE;
+      mi_group_set_ray_batch(group, batch);
+      if (mi_group_render(group, mode, rayStream.data(), rayStream.size(), rayFunc ? &IpuScene::trampoline : nullptr, this) != MI_OK)
+        return fail("render");
+      traceTimeSecs = mi_group_trace_time_secs(group);
+      return EXIT_SUCCESS;
+    }
     data.device = config.device;
     if (mi_scene_create(&data, &scene) != MI_OK) return fail("scene creation");
-    if (nif) {
-      mi_nif_desc d{};
-      mi_host_nif_describe(nif, &d);
-      if (mi_scene_set_nif(scene, d.num_layers, d.kernels, d.biases, d.rows, d.cols, d.relu, d.embedding_dimension,
-                           d.max_value, d.mean, d.log_tonemap) != MI_OK) return fail("NIF upload");
-    }
-    mi_scene_set_hdri_rotation(scene, hdriRotationDegrees);
-    mi_scene_set_max_nif_batch(scene, nifMaxRaysPerBatch);
-    // batch = 1440 compute tiles x 6 workers x raysPerWorker rays, as on one IPU (src/IpuScene.cpp:360-361)
-    if (rayFunc) mi_scene_set_ray_batch(scene, (size_t)1440 * 6 * (maxRaysPerWorker ? maxRaysPerWorker : 1));
-    const int mode = data.path_trace ? MI_MODE_PATH_TRACE : MI_MODE_SHADOW_TRACE;
+    if (!configure(scene)) return EXIT_FAILURE;
+    if (rayFunc) mi_scene_set_ray_batch(scene, batch);
     if (mi_render(scene, mode, rayStream.data(), rayStream.size(), rayFunc ? &IpuScene::trampoline : nullptr, this) != MI_OK)
       return fail("render");
     traceTimeSecs = mi_trace_time_secs(scene);
     return EXIT_SUCCESS;
   }
 
-  uint64_t rayCasts() const { uint64_t c[4] = {0, 0, 0, 0}; if (scene) mi_get_counters(scene, c); return c[0]; }
+  uint64_t rayCasts() const {
+    uint64_t c[4] = {0, 0, 0, 0};
+    if (group) mi_group_get_counters(group, c); else if (scene) mi_get_counters(scene, c);
+    return c[0];
+  }
+  // RCCL send/recv pairs, peer copies and bands of the last multi-replica render (zeros for a single scene)
+  void lastTransfer(uint64_t info[3]) const { info[0] = info[1] = info[2] = 0; if (group) mi_group_last_transfer(group, info); }
 
  private:
   static void trampoline(void* user, size_t batch, const mi_trace_result* rays, size_t count) {
     auto* self = static_cast<IpuScene*>(user);
     std::vector<mi_trace_result> v(rays, rays + count);
     (*self->rayFunc)(batch, v);
+  }
+  void release() {
+    if (scene) { mi_scene_destroy(scene); scene = nullptr; }
+    if (group) { mi_group_destroy(group); group = nullptr; }
+  }
+  bool configure(mi_scene* s) {
+    if (nif) {
+      mi_nif_desc d{};
+      mi_host_nif_describe(nif, &d);
+      if (mi_scene_set_nif(s, d.num_layers, d.kernels, d.biases, d.rows, d.cols, d.relu, d.embedding_dimension,
+                           d.max_value, d.mean, d.log_tonemap) != MI_OK) { fail("NIF upload"); return false; }
+    }
+    mi_scene_set_hdri_rotation(s, hdriRotationDegrees);
+    mi_scene_set_max_nif_batch(s, nifMaxRaysPerBatch);
+    return true;
   }
   int fail(const char* what) {
     std::fprintf(stderr, "[error] %s failed: %s\n", what, mi_last_error());
@@ -109,6 +142,7 @@ class IpuScene {
   std::size_t maxRaysPerWorker;
   RuntimeConfig config;
   mi_scene* scene = nullptr;
+  mi_group* group = nullptr;
   double traceTimeSecs = 0.0;
   float hdriRotationDegrees = 0.f;
   std::size_t nifMaxRaysPerBatch = 0;

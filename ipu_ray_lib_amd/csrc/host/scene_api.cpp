@@ -1,5 +1,7 @@
 // scene_api.cpp — C ABI of the host scene plumbing (include/mi_scene_host.h).
+#include <algorithm>
 #include <cstring>
+#include <vector>
 #include <limits>
 #include <stdexcept>
 #include <string>
@@ -7,6 +9,7 @@
 #include "../../../include/mi_scene_host.h"
 #include "scene_types.hpp"
 #include "../scene_blob.hpp"
+#include "../ray_shard.hpp"
 
 using namespace mi;
 using namespace mi::host;
@@ -190,6 +193,31 @@ int mi_scene_deserialise(const uint8_t* blob, size_t size, mi_scene_desc* d, siz
     const size_t used = mi::blob::deserialiseScene(blob, size, *d, 16);
     if (consumed) *consumed = used;
   });
+}
+
+size_t mi_shard_band_rays(size_t n, uint32_t window_w) { return mi::shard::band_rays(n, window_w); }
+
+size_t mi_shard_count(size_t n, size_t band, uint32_t replicas, uint32_t r) { return mi::shard::replica_count(n, band, replicas, r); }
+
+int mi_shard_stream_index(size_t n, size_t band, uint32_t replicas, uint32_t r, uint64_t* out, size_t capacity) {
+  if (!out || band == 0 || replicas == 0 || r >= replicas) { g_err = "mi_shard_stream_index: bad argument"; return MI_ERR_INVALID_ARG; }
+  if (capacity < mi::shard::replica_count(n, band, replicas, r)) { g_err = "mi_shard_stream_index: output too small"; return MI_ERR_INVALID_ARG; }
+  size_t k = 0;
+  for (size_t b = r; b * band < n; b += replicas)
+    for (size_t i = b * band; i < std::min(n, (b + 1) * band); ++i) out[k++] = i;
+  return MI_OK;
+}
+
+int mi_shard_frame_index(size_t n, size_t band, uint32_t replicas, uint64_t* out) {
+  if (!out || band == 0 || replicas == 0) { g_err = "mi_shard_frame_index: bad argument"; return MI_ERR_INVALID_ARG; }
+  std::vector<size_t> offset(replicas + 1, 0);
+  for (uint32_t r = 0; r < replicas; ++r) offset[r + 1] = offset[r] + mi::shard::replica_count(n, band, replicas, r);
+  for (size_t i = 0; i < n; ++i) {
+    uint32_t r; size_t pos;
+    mi::shard::locate(band, replicas, i, r, pos);
+    out[i] = offset[r] + pos;
+  }
+  return MI_OK;
 }
 
 uint32_t mi_blob_padding(uint32_t base_align, size_t offset, uint32_t align) {

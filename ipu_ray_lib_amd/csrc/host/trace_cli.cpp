@@ -23,7 +23,8 @@ namespace {
 
 struct Options {
   std::string outprefix = "out", crop, meshFile, nifHdri, scene = "box", visualise = "rgb", renderMode = "path-trace", logLevel = "info";
-  uint32_t gpus = 1;
+  uint32_t gpus = 1, replicas = 0;
+  int transport = 0;
   size_t raysPerWorker = 1, maxNifBatch = 0;
   int width = 768, height = 432;
   float antiAlias = .25f, hdriRotation = 0.f, availableMemoryProportion = 0.6f;
@@ -35,8 +36,12 @@ struct Options {
 const char* kHelp =
     "  --help                              Show command help.\n"
     "  -o [ --outprefix ] arg (=out)       Set the output filename prefix.\n"
-    "  --gpus arg (=1)                     Select number of GPUs (alias: --ipus; each GPU renders a share of the ray stream).\n"
-    "  --rays-per-worker arg (=1)          Accepted for compatibility (IPU batching knob; no effect).\n"
+    "  --gpus arg (=1)                     Select number of GPUs (alias: --ipus). The ray stream is dealt to them in bands of 8\n"
+    "                                      image rows; the frame is assembled on the first GPU with one RCCL gather.\n"
+    "  --replicas arg (=gpus)              Scene replicas the stream is dealt to (replica i runs on GPU i mod gpus).\n"
+    "  --gather arg (=auto)                How the replicas' results reach the first GPU: auto | rccl | copy.\n"
+    "  --rays-per-worker arg (=1)          With --ipu-ray-callback: the ray batch the callback is called for is\n"
+    "                                      1440 x 6 x this many rays (one IPU's batch); no effect otherwise.\n"
     "  -w [ --width ] arg (=768)           Set rendered image width.\n"
     "  -h [ --height ] arg (=432)          Set rendered image height.\n"
     "  --crop arg                          Window of the image to render: wxh+c+r.\n"
@@ -81,6 +86,8 @@ Options parse(int argc, char** argv) {
     if (a == "--help") { std::printf("%s", kHelp); throw std::runtime_error("Show help"); }
     else if (a == "-o" || a == "--outprefix") o.outprefix = need(i);
     else if (a == "--gpus" || a == "--ipus") o.gpus = (uint32_t)std::stoul(need(i));
+    else if (a == "--replicas") o.replicas = (uint32_t)std::stoul(need(i));
+    else if (a == "--gather") { const std::string g = need(i); if (g == "auto") o.transport = 0; else if (g == "rccl") o.transport = 1; else if (g == "copy") o.transport = 2; else throw std::runtime_error("the argument for option '--gather' is invalid"); }
     else if (a == "--rays-per-worker") o.raysPerWorker = std::stoul(need(i));
     else if (a == "-w" || a == "--width") o.width = std::stoi(need(i));
     else if (a == "-h" || a == "--height") o.height = std::stoi(need(i));
@@ -243,7 +250,7 @@ int main(int argc, char** argv) {
   std::vector<mi_sphere> spheres(sceneRef.spheres, sceneRef.spheres + sceneRef.num_spheres);
   std::vector<mi_disc> discs(sceneRef.discs, sceneRef.discs + sceneRef.num_discs);
   mi::IpuScene gpuScene(spheres, discs, sceneRef, rayStream, args.raysPerWorker, args.rayCallback ? &cb : nullptr);
-  mi::RuntimeConfig rc; rc.numGpus = args.gpus; rc.numReplicas = args.gpus;
+  mi::RuntimeConfig rc; rc.numGpus = args.gpus; rc.numReplicas = args.replicas ? args.replicas : args.gpus; rc.transport = args.transport;
   gpuScene.setRuntimeConfig(rc);
   if (!args.nifHdri.empty()) gpuScene.loadNifModel(args.nifHdri);
   gpuScene.setHdriRotation(args.hdriRotation);
@@ -259,6 +266,12 @@ int main(int argc, char** argv) {
   logf(2, "info", "GPU time: %g", secs);
   logf(2, "info", "GPU %s per second: %g", sceneRef.path_trace ? "paths" : "rays", rayStream.size() * castsPerRay / secs);
   logf(2, "info", "GPU ray casts per second: %g", (double)gpuScene.rayCasts() / secs);
+  {
+    uint64_t moved[3];
+    gpuScene.lastTransfer(moved);
+    if (moved[2]) logf(2, "info", "Replicas: %u on %u GPU(s); %llu bands dealt, gathered with %llu RCCL send/recv pairs and %llu peer copies", rc.numReplicas, rc.numGpus,
+                       (unsigned long long)moved[2], (unsigned long long)moved[0], (unsigned long long)moved[1]);
+  }
 
   std::vector<float> image;
   const unsigned hitCount = visualise(rayStream, sceneRef, args.visualise, args.width, args.height, image);

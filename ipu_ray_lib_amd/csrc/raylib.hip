@@ -722,3 +722,5 @@ int mi_nif_infer_device(mi_scene* scene, const float* d_u, const float* d_v, flo
 }
 
 }  // extern "C"
+
+#include "group_render.hpp"

@@ -114,3 +114,28 @@ def test_cli_rejects_bad_flags_without_gpu():
                       (["--log-level", "loud"], "log-level"), (["--nope"], "unrecognised")):
         r = subprocess.run([str(TRACE)] + argv, capture_output=True, text=True)
         assert r.returncode != 0 and msg in r.stderr
+
+
+def _render_exr(tmp_path, tag, *extra):
+    prefix = tmp_path / tag
+    r = subprocess.run([str(TRACE), "--scene", "box", "-w", "200", "-h", "144", "--samples", "12", "--mesh-file", str(irl.DEFAULT_MESH),
+                        "-o", str(prefix), *extra], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    return Path(str(prefix) + "_rgb_gpu.exr").read_bytes(), r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_replicas_give_the_byte_identical_exr(tmp_path):
+    """`trace --replicas R` (the C++ multi-GPU path of mi::IpuScene: bands dealt to R scene replicas, one RCCL gather;
+    on a one-GPU box the replicas share GPU 0 and the RCCL peers are the root's own rank) must write the same EXR,
+    byte for byte, as the single-scene render; so must `--gpus N` on a box that has N GPUs."""
+    import torch
+    one, _ = _render_exr(tmp_path, "one")
+    two, log = _render_exr(tmp_path, "two", "--replicas", "2", "--gather", "rccl")
+    assert two == one and "1 RCCL send/recv pairs" in log, log
+    three, log = _render_exr(tmp_path, "three", "--replicas", "3", "--gather", "copy", "--ipu-ray-callback")
+    assert three == one and "2 peer copies" in log, log
+    n_dev = torch.cuda.device_count()
+    if n_dev >= 2:
+        many, log = _render_exr(tmp_path, "many", "--gpus", str(n_dev))
+        assert many == one and f"{n_dev - 1} RCCL send/recv pairs" in log, log

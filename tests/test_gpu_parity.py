@@ -815,3 +815,56 @@ def test_one_scene_on_two_streams_concurrently(scenes):
             assert_streams_identical(got, want, "two streams of one scene")
     dev.close()
     d.set_image(96, 64); d.samples_per_pixel = 5
+
+
+# ------------------------------------------------------------------------------------------------------
+# several replicas in one process (mi_group_*): dealt in 8-row bands, gathered with one RCCL group call
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("replicas,transport", [(2, "rccl"), (3, "rccl"), (3, "copy"), (1, "auto")])
+def test_replica_group_renders_the_single_scene_frame(scenes, replicas, transport):
+    """The C++ multi-GPU path on ONE device: R replicas of the scene share GPU 0, the stream is dealt to them in
+    8-row bands, every share is traced on its own stream, and the shares reach the root replica through RCCL
+    (ncclSend / ncclRecv inside one group call; on one device the peers are the root's own rank) or through peer
+    copies; the de-interleaved frame must equal the single-scene render and the oracle, byte for byte - path trace
+    (ragged last band: 100 rows) and shadow trace, with the partial-result callback."""
+    s = scenes["box"]; d = s.desc
+    d.set_image(136, 100); d.samples_per_pixel = 9; d.path_trace = 1
+    want = s.init_ray_stream(); st = ol.path_trace_pixel_rng(d, want, 16)
+    code = {"auto": irl.TRANSPORT_AUTO, "rccl": irl.TRANSPORT_RCCL, "copy": irl.TRANSPORT_COPY}[transport]
+    grp = irl.IpuGroup(d, [0] * replicas, code)
+    got = s.init_ray_stream()
+    seen = []
+    grp.setRayBatch(5000)
+    grp.run(got, irl.MODE_PATH_TRACE, callback=lambda idx, first, cnt: seen.append((idx, first, cnt)))
+    assert_streams_identical(got, want, f"{replicas} replicas, {transport}")
+    assert grp.counters()["casts"] == st.casts and grp.counters()["paths"] == got.size * 9
+    assert seen == [(b, b * 5000, min(5000, got.size - b * 5000)) for b in range((got.size + 4999) // 5000)]
+    moved = grp.last_transfer()
+    assert moved["bands"] == 13                                     # 100 rows = 12 bands of 8 + one of 4
+    if replicas > 1:
+        assert (moved["rccl_messages"], moved["peer_copies"]) == ((replicas - 1, 0) if transport == "rccl" else (0, replicas - 1))
+    # shadow trace through the same group, twice (buffers and communicators are reused)
+    d.path_trace = 0
+    for _ in range(2):
+        g2 = s.init_ray_stream(); w2 = g2.copy()
+        grp.run(g2, irl.MODE_SHADOW_TRACE); ol.shadow_trace(d, w2, 16)
+        assert_streams_identical(g2, w2, f"shadow trace, {replicas} replicas, {transport}")
+    grp.close()
+    d.path_trace = 1; d.set_image(96, 64); d.samples_per_pixel = 5
+
+
+def test_replica_group_on_every_visible_gpu(scenes):
+    """One replica per visible GPU (skipped on a one-GPU box): RCCL between real peers."""
+    import torch
+    n_dev = torch.cuda.device_count()
+    if n_dev < 2:
+        pytest.skip("needs at least two GPUs")
+    s = scenes["box"]; d = s.desc
+    d.set_image(256, 200); d.samples_per_pixel = 6; d.path_trace = 1
+    want = s.init_ray_stream(); ol.path_trace_pixel_rng(d, want, 16)
+    grp = irl.IpuGroup(d, list(range(n_dev)))
+    got = s.init_ray_stream(); grp.run(got, irl.MODE_PATH_TRACE)
+    assert_streams_identical(got, want, f"{n_dev} GPUs")
+    assert grp.last_transfer()["rccl_messages"] == n_dev - 1
+    grp.close()
+    d.set_image(96, 64); d.samples_per_pixel = 5

@@ -13,7 +13,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = Path(__file__).resolve().parent.parent
-W, H, SPP = 40, 52, 3        # 52 rows: 4 tiles of 16 (ragged last tile) -> ranks get different pixel counts
+W, H, SPP = 40, 52, 3        # 52 rows: 6 bands of 8 + one of 4 (ragged last band) -> ranks get different pixel counts
 
 
 def _stream(irl, rows, cols):
@@ -42,6 +42,29 @@ def _worker(rank, world, port, out_path):
         np.save(out_path, frame.numpy())
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_band_dealing_is_a_partition_and_matches_an_independent_restatement():
+    """The C definition every multi-GPU path shares (csrc/ray_shard.hpp through mi_shard_*): band b of `band`
+    consecutive rays belongs to replica b % R. Checked against a numpy restatement for row-structured and
+    unstructured streams, ragged last bands, more replicas than bands, and the frame (de-interleave) index."""
+    from ipu_ray_lib_amd import sharding
+    for n, width in ((40 * 52, 40), (1440 * 24, 1440), (17 * 5, 17), (10001, 0), (4096 * 3 + 5, 7), (5, 5), (1, 1)):
+        band = sharding.band_rays(n, width)
+        assert band == (8 * width if width and n % width == 0 else 4096)
+        for world in (1, 2, 3, 4, 8, 13):
+            want_owner = (np.arange(n) // band) % world
+            seen = np.zeros(n, int)
+            gathered = []
+            for r in range(world):
+                idx = sharding.rank_stream_index(n, band, world, r).astype(np.int64)
+                assert idx.size == sharding.rank_count(n, band, world, r) == int((want_owner == r).sum())
+                assert np.array_equal(idx, np.nonzero(want_owner == r)[0])          # a rank's stream keeps stream order
+                seen[idx] += 1
+                gathered.append(idx)
+            assert (seen == 1).all()
+            fi = sharding.frame_index(n, band, world).astype(np.int64)
+            assert np.array_equal(np.concatenate(gathered)[fi], np.arange(n))     # gathered[fi[i]] is stream ray i
 
 
 def test_two_rank_tiles_and_single_gather(tmp_path):
