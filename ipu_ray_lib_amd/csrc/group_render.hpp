@@ -173,12 +173,21 @@ void groupRender(mi_group& G, int mode, mi_trace_result* rays, size_t n, mi_ray_
     G.lastRcclMessages = G.lastCopyMessages = 0;
     if (R > 1) {
       if (G.useRccl) {
+        // Inside the group call every communicator (= device) uses ONE stream: that of the device's first replica,
+        // which first waits for the device's other replicas to finish tracing.
+        std::vector<hipStream_t> commStream(G.commDevices.size(), nullptr);
+        for (uint32_t r = 0; r < R; ++r) {
+          mi_group::Replica& P = G.replicas[r];
+          if (!commStream[P.rank]) { commStream[P.rank] = P.stream; continue; }
+          HIP_CHECK(hipSetDevice(P.device));
+          HIP_CHECK(hipStreamWaitEvent(commStream[P.rank], P.done, 0));
+        }
         RCCL_CHECK(G, G.rccl.groupStart());
         for (uint32_t r = 1; r < R; ++r) {
           mi_group::Replica& P = G.replicas[r];
           if (count[r] == 0) continue;
           const size_t bytes = count[r] * sizeof(mi_trace_result);
-          RCCL_CHECK(G, G.rccl.send(P.d_share, bytes, ncclUint8, root.rank, G.comms[P.rank], P.stream));
+          RCCL_CHECK(G, G.rccl.send(P.d_share, bytes, ncclUint8, root.rank, G.comms[P.rank], commStream[P.rank]));
           RCCL_CHECK(G, G.rccl.recv(G.d_gather + offset[r], bytes, ncclUint8, P.rank, G.comms[root.rank], root.stream));
           ++G.lastRcclMessages;
         }
