@@ -96,7 +96,11 @@ AccessorView accessor(const Glb& g, size_t index) {
   return v;
 }
 
-void collect(const Glb& g, size_t nodeIndex, const Mat4& parent, bool loadNormals, std::vector<TriMesh>& out) {
+void collect(const Glb& g, size_t nodeIndex, const Mat4& parent, bool loadNormals, std::vector<TriMesh>& out, std::vector<uint8_t>& onPath) {
+  // the node hierarchy must be a forest: a node that is its own ancestor would recurse for ever
+  if (nodeIndex >= onPath.size()) throw std::runtime_error("glb: node index out of range");
+  if (onPath[nodeIndex]) throw std::runtime_error("glb: node hierarchy contains a cycle");
+  onPath[nodeIndex] = 1;
   const auto& node = g.doc->at("nodes").at(nodeIndex);
   const Mat4 world = mul(parent, nodeLocalMatrix(node));
   if (node.has("mesh")) {
@@ -118,6 +122,8 @@ void collect(const Glb& g, size_t nodeIndex, const Mat4& parent, bool loadNormal
       }
       if (loadNormals && prim.at("attributes").has("NORMAL")) {
         const AccessorView nrm = accessor(g, (size_t)prim.at("attributes").at("NORMAL").number());
+        if (nrm.componentType != 5126 || nrm.numComp != 3) throw std::runtime_error("glb: NORMAL must be float VEC3");
+        if (nrm.count != pos.count) throw std::runtime_error("glb: NORMAL count differs from POSITION count");
         for (size_t i = 0; i < nrm.count; ++i) {
           float v[3]; memcpy(v, nrm.base + i * nrm.stride, 12);
           const float* m = world.m;   // rigid node transforms only: rotation part applies to normals
@@ -136,6 +142,7 @@ void collect(const Glb& g, size_t nodeIndex, const Mat4& parent, bool loadNormal
           else if (idx.componentType == 5125) { memcpy(&v, src, 4); }
           else if (idx.componentType == 5121) { v = *src; }
           else throw std::runtime_error("glb: unsupported index type");
+          if (v >= pos.count) throw std::runtime_error("glb: triangle index " + std::to_string(v) + " out of range (mesh has " + std::to_string(pos.count) + " vertices)");
           tm.indices.push_back((uint16_t)v);
         }
       } else {
@@ -147,7 +154,8 @@ void collect(const Glb& g, size_t nodeIndex, const Mat4& parent, bool loadNormal
   }
   if (node.has("children"))
     for (size_t c = 0; c < node.at("children").size(); ++c)
-      collect(g, (size_t)node.at("children").at(c).number(), world, loadNormals, out);
+      collect(g, (size_t)node.at("children").at(c).number(), world, loadNormals, out, onPath);
+  onPath[nodeIndex] = 0;
 }
 
 }  // namespace
@@ -157,7 +165,8 @@ std::vector<TriMesh> loadGlbMeshes(const std::string& path, bool loadNormals) {
   std::vector<TriMesh> meshes;
   const size_t sceneIndex = g.doc->has("scene") ? (size_t)g.doc->at("scene").number() : 0;
   const auto& roots = g.doc->at("scenes").at(sceneIndex).at("nodes");
-  for (size_t i = 0; i < roots.size(); ++i) collect(g, (size_t)roots.at(i).number(), identity(), loadNormals, meshes);
+  std::vector<uint8_t> onPath(g.doc->at("nodes").size(), 0);
+  for (size_t i = 0; i < roots.size(); ++i) collect(g, (size_t)roots.at(i).number(), identity(), loadNormals, meshes, onPath);
   return meshes;
 }
 

@@ -242,6 +242,9 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
   need(N == 0 || skip[0] == N, "BVH root does not span the node array");
   for (uint32_t i = 0; i < N; ++i) {
     const mi_bvh_node& n = d.bvh_nodes[i];
+    // the box test's fast form assumes finite slab products (trace_wavefront.hpp): a NaN / inf box is a malformed scene
+    need(std::isfinite(n.min_x) && std::isfinite(n.min_y) && std::isfinite(n.min_z), "BVH node bounds are not finite");
+    need((n.dx & 0x7C00u) != 0x7C00u && (n.dy & 0x7C00u) != 0x7C00u && (n.dz & 0x7C00u) != 0x7C00u, "BVH node extents are not finite");
     GNode g;
     g.minx = n.min_x; g.miny = n.min_y; g.minz = n.min_z;
     g.maxx = n.min_x + half_bits_to_float(n.dx);                  // CompactBVH2Node.cpp:8-10, one rounded add each

@@ -5,7 +5,7 @@
 // defined in the reference checkout, compiled from where it lies (see oracle/Makefile, target
 // `ref`). Only reference files that compile in this image without any stand-in header are
 // reachable: ext/math/sincos.cpp, include/xoshiro.hpp, include/embree_utils/geometry.hpp,
-// include/geometric_sampling.hpp, include/BxDF.hpp. Everything that includes
+// include/geometric_sampling.hpp, include/BxDF.hpp, include/Material.hpp (it includes only geometry.hpp). Everything that includes
 // include/precision_utils.hpp needs Eigen::half (absent here) and is NOT built.
 // Outputs go to oracle/_ref/ (git-ignored); never shipped as product.
 
@@ -15,6 +15,8 @@
 #include <embree_utils/geometry.hpp>
 #include <xoshiro.hpp>
 #include <BxDF.hpp>          // pulls geometric_sampling.hpp and math/sincos.hpp
+#include <Material.hpp>
+#include <new>
 
 using embree_utils::Vec3fa;
 
@@ -94,6 +96,70 @@ void ref_layout(uint32_t* out) {
   out[7] = offsetof(embree_utils::HitRecord, primID); out[8] = offsetof(embree_utils::HitRecord, normal);
   out[9] = offsetof(embree_utils::HitRecord, throughput); out[10] = offsetof(embree_utils::HitRecord, geomID);
   out[11] = offsetof(embree_utils::HitRecord, flags);
+}
+
+// ---- Material (include/Material.hpp:8-35) ----
+// out: sizeof, alignof, offsets of albedo / ior / emission / type / emissive, the three Type values
+void ref_material_layout(uint32_t* out) {
+  out[0] = sizeof(Material); out[1] = alignof(Material);
+  out[2] = offsetof(Material, albedo); out[3] = offsetof(Material, ior); out[4] = offsetof(Material, emission);
+  out[5] = offsetof(Material, type); out[6] = offsetof(Material, emissive);
+  out[7] = (uint32_t)Material::Type::Diffuse; out[8] = (uint32_t)Material::Type::Specular; out[9] = (uint32_t)Material::Type::Refractive;
+  out[10] = sizeof(Material::Type);
+}
+// raw bytes of Material() and of Material(albedo, emission, type), constructed over memory pre-filled with `fill`
+void ref_material_default(uint8_t fill, uint8_t* bytes) {
+  alignas(Material) uint8_t buf[sizeof(Material)];
+  memset(buf, fill, sizeof buf);
+  new (buf) Material();
+  memcpy(bytes, buf, sizeof buf);
+}
+void ref_material_make(const float* albedo, const float* emission, uint32_t type, uint8_t fill, uint8_t* bytes) {
+  alignas(Material) uint8_t buf[sizeof(Material)];
+  memset(buf, fill, sizeof buf);
+  new (buf) Material(Vec3fa(albedo[0], albedo[1], albedo[2]), Vec3fa(emission[0], emission[1], emission[2]), (Material::Type)type);
+  memcpy(bytes, buf, sizeof buf);
+}
+
+// ---- Ray / HitRecord / TraceResult / PixelCoord constructors (geometry.hpp:199-259) ----
+void ref_ray_ctor(const float* o, const float* d, uint8_t fill, uint8_t* bytes) {
+  alignas(embree_utils::Ray) uint8_t buf[sizeof(embree_utils::Ray)];
+  memset(buf, fill, sizeof buf);
+  new (buf) embree_utils::Ray(Vec3fa(o[0], o[1], o[2]), Vec3fa(d[0], d[1], d[2]));
+  memcpy(bytes, buf, sizeof buf);
+}
+void ref_hitrecord_ctor(const float* o, const float* d, uint8_t fill, uint8_t* bytes) {
+  alignas(embree_utils::HitRecord) uint8_t buf[sizeof(embree_utils::HitRecord)];
+  memset(buf, fill, sizeof buf);
+  new (buf) embree_utils::HitRecord(Vec3fa(o[0], o[1], o[2]), Vec3fa(d[0], d[1], d[2]));
+  memcpy(bytes, buf, sizeof buf);
+}
+void ref_traceresult_ctor(const float* o, const float* d, uint32_t u, uint32_t v, uint8_t fill, uint8_t* bytes) {
+  alignas(embree_utils::TraceResult) uint8_t buf[sizeof(embree_utils::TraceResult)];
+  memset(buf, fill, sizeof buf);
+  new (buf) embree_utils::TraceResult(embree_utils::HitRecord(Vec3fa(o[0], o[1], o[2]), Vec3fa(d[0], d[1], d[2])), embree_utils::PixelCoord(u, v));
+  memcpy(bytes, buf, sizeof buf);
+}
+void ref_pixelcoord_default(float* uv) { embree_utils::PixelCoord p; uv[0] = p.u; uv[1] = p.v; }
+// HitRecord constants: ERROR, ESCAPED, InvalidGeomID, InvalidPrimID
+void ref_hit_constants(uint32_t* out) {
+  out[0] = embree_utils::HitRecord::ERROR; out[1] = embree_utils::HitRecord::ESCAPED;
+  out[2] = embree_utils::HitRecord::InvalidGeomID; out[3] = embree_utils::HitRecord::InvalidPrimID;
+}
+
+// ---- Vec3fa::permute / abs / min / max / isNonZero, Bounds3d (geometry.hpp:95-197) ----
+void ref_permute(const float* v, uint32_t ix, uint32_t iy, uint32_t iz, float* out) {
+  Vec3fa r = Vec3fa(v[0], v[1], v[2]).permute(ix, iy, iz); out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void ref_abs(const float* v, float* out) { Vec3fa r = Vec3fa(v[0], v[1], v[2]).abs(); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+int ref_is_non_zero(const float* v) { return Vec3fa(v[0], v[1], v[2]).isNonZero() ? 1 : 0; }
+void ref_bounds_default(float* out) { embree_utils::Bounds3d b; out[0] = b.min.x; out[1] = b.min.y; out[2] = b.min.z; out[3] = b.max.x; out[4] = b.max.y; out[5] = b.max.z; }
+// (a += b) then centroid: out = min, max, centroid
+void ref_bounds_union(const float* a, const float* b, float* out) {
+  embree_utils::Bounds3d A(Vec3fa(a[0], a[1], a[2]), Vec3fa(a[3], a[4], a[5])), B(Vec3fa(b[0], b[1], b[2]), Vec3fa(b[3], b[4], b[5]));
+  A += B;
+  const Vec3fa c = A.centroid();
+  out[0] = A.min.x; out[1] = A.min.y; out[2] = A.min.z; out[3] = A.max.x; out[4] = A.max.y; out[5] = A.max.z; out[6] = c.x; out[7] = c.y; out[8] = c.z;
 }
 
 } // extern "C"

@@ -3,7 +3,7 @@
 
 Run in the build container only (needs /root/reference): `make -C oracle ref` compiles the
 reference's Eigen-free L0 sources where they lie (ext/math/sincos.cpp, include/xoshiro.hpp,
-include/embree_utils/geometry.hpp, include/geometric_sampling.hpp, include/BxDF.hpp) behind the
+include/embree_utils/geometry.hpp, include/geometric_sampling.hpp, include/BxDF.hpp, include/Material.hpp) behind the
 thin extern "C" driver oracle/ref_driver.cpp. This script drives that library with seeded inputs
 and stores inputs + outputs as DATA. No reference source text is stored.
 """
@@ -106,6 +106,57 @@ def main():
 
     lay = (C.c_uint32 * 12)(); r.ref_layout(lay)
     out["layout"] = np.array(list(lay), dtype=np.uint32)
+
+    # ---- Material, constructors, constants, permute / abs / bounds (everything else that compiles here) ----
+    def raw(fn, size, *args):
+        """Bytes an object holds after construction over 0x00- and over 0xFF-filled memory; bytes that differ were
+        never written by the constructor (padding, or members the constructor leaves uninitialised)."""
+        a = (C.c_uint8 * size)(); b = (C.c_uint8 * size)()
+        fn(*args, 0x00, a); fn(*args, 0xFF, b)
+        a = np.frombuffer(bytes(a), np.uint8); b = np.frombuffer(bytes(b), np.uint8)
+        return a.copy(), (a == b)
+
+    ml = (C.c_uint32 * 11)(); r.ref_material_layout(ml)
+    out["material_layout"] = np.array(list(ml), dtype=np.uint32)
+    msize = int(ml[0])
+    md, md_init = raw(r.ref_material_default, msize)
+    out.update(material_default=md, material_default_init=md_init)
+    mats_in = np.zeros((40, 7), np.float32)
+    mats_in[:, :3] = rng.random((40, 3)); mats_in[:, 3:6] = rng.random((40, 3)) * (rng.random((40, 1)) < 0.5); mats_in[:, 6] = rng.integers(0, 3, 40)
+    mats_in[0, 3:6] = 0; mats_in[1, 3:6] = [0, 0, 1e-30]; mats_in[2, 3:6] = [-0.0, 0, 0]
+    mats_bytes = np.zeros((40, msize), np.uint8); mats_init = np.zeros((40, msize), bool)
+    for i, m in enumerate(mats_in):
+        mats_bytes[i], mats_init[i] = raw(r.ref_material_make, msize, arr3(m[:3]), arr3(m[3:6]), int(m[6]))
+    out.update(material_in=mats_in, material_bytes=mats_bytes, material_init=mats_init)
+
+    od = rng.normal(size=(16, 6)).astype(np.float32); uv = rng.integers(0, 5000, (16, 2)).astype(np.uint32)
+    ray_b = np.zeros((16, 32), np.uint8); ray_i = np.zeros((16, 32), bool)
+    hit_b = np.zeros((16, 64), np.uint8); hit_i = np.zeros((16, 64), bool)
+    tr_b = np.zeros((16, 84), np.uint8); tr_i = np.zeros((16, 84), bool)
+    for i in range(16):
+        ray_b[i], ray_i[i] = raw(r.ref_ray_ctor, 32, arr3(od[i, :3]), arr3(od[i, 3:]))
+        hit_b[i], hit_i[i] = raw(r.ref_hitrecord_ctor, 64, arr3(od[i, :3]), arr3(od[i, 3:]))
+        tr_b[i], tr_i[i] = raw(lambda o, d, f, b: r.ref_traceresult_ctor(o, d, int(uv[i, 0]), int(uv[i, 1]), f, b), 84, arr3(od[i, :3]), arr3(od[i, 3:]))
+    out.update(ctor_od=od, ctor_uv=uv, ray_bytes=ray_b, ray_init=ray_i, hit_bytes=hit_b, hit_init=hit_i, trace_bytes=tr_b, trace_init=tr_i)
+    pc = (f32 * 2)(); r.ref_pixelcoord_default(pc); out["pixelcoord_default"] = np.array(list(pc), np.float32)
+    hc = (C.c_uint32 * 4)(); r.ref_hit_constants(hc); out["hit_constants"] = np.array(list(hc), np.uint32)
+
+    pv = rng.normal(size=(8, 3)).astype(np.float32); pv[0] = [-0.0, 2.5, -3.5]
+    perm = np.zeros((8, 27, 3), np.float32); ab = np.zeros((8, 3), np.float32); nz = np.zeros(8, np.int32)
+    for i in range(8):
+        for k in range(27):
+            o = (f32 * 3)(); r.ref_permute(arr3(pv[i]), k // 9, (k // 3) % 3, k % 3, o); perm[i, k] = list(o)
+        o = (f32 * 3)(); r.ref_abs(arr3(pv[i]), o); ab[i] = list(o)
+    nzv = np.array([[0, 0, 0], [-0.0, 0, 0], [0, 1e-45, 0], [0, 0, 1], [np.nan, 0, 0]], np.float32)
+    nz = np.array([r.ref_is_non_zero(arr3(v)) for v in nzv], np.int32)
+    out.update(permute_v=pv, permute_out=perm, abs_out=ab, nonzero_v=nzv, nonzero_out=nz)
+    bd = (f32 * 6)(); r.ref_bounds_default(bd); out["bounds_default"] = np.array(list(bd), np.float32)
+    bl = rng.normal(size=(32, 2, 3)).astype(np.float32); bh = bl + rng.random((32, 2, 3)).astype(np.float32) * 3
+    bu = np.zeros((32, 9), np.float32)
+    for i in range(32):
+        o = (f32 * 9)()
+        r.ref_bounds_union((f32 * 6)(*bl[i, 0], *bh[i, 0]), (f32 * 6)(*bl[i, 1], *bh[i, 1]), o); bu[i] = list(o)
+    out.update(bounds_lo=bl, bounds_hi=bh, bounds_union=bu)
 
     dst = Path(__file__).with_name("ref_l0_vectors.npz")
     np.savez_compressed(dst, **out)

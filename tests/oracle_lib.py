@@ -144,6 +144,20 @@ def ref_lib():
     r.ref_dielectric.argtypes = [pf, pf, pf, f32, f32, pf]; r.ref_dielectric.restype = C.c_int
     r.ref_evaluate_roulette.argtypes = [f32, pf]; r.ref_evaluate_roulette.restype = C.c_int
     r.ref_layout.argtypes = [C.POINTER(u32)]
+    pb = C.POINTER(C.c_uint8)
+    r.ref_material_layout.argtypes = [C.POINTER(u32)]
+    r.ref_material_default.argtypes = [C.c_uint8, pb]
+    r.ref_material_make.argtypes = [pf, pf, u32, C.c_uint8, pb]
+    r.ref_ray_ctor.argtypes = [pf, pf, C.c_uint8, pb]
+    r.ref_hitrecord_ctor.argtypes = [pf, pf, C.c_uint8, pb]
+    r.ref_traceresult_ctor.argtypes = [pf, pf, u32, u32, C.c_uint8, pb]
+    r.ref_pixelcoord_default.argtypes = [pf]
+    r.ref_hit_constants.argtypes = [C.POINTER(u32)]
+    r.ref_permute.argtypes = [pf, u32, u32, u32, pf]
+    r.ref_abs.argtypes = [pf, pf]
+    r.ref_is_non_zero.argtypes = [pf]; r.ref_is_non_zero.restype = C.c_int
+    r.ref_bounds_default.argtypes = [pf]
+    r.ref_bounds_union.argtypes = [pf, pf, pf]
     return r
 
 

@@ -112,6 +112,24 @@ def test_path_trace_bit_exact(scenes, name, size, spp, kernel):
     dev.close()
 
 
+def test_nif_demo_collada_scene():
+    """assets/hdri_test.dae (the reference's NIF demo geometry, 6 meshes / 5 656 triangles, no emitter) with and without
+    vertex normals: shadow trace and path trace, every TraceResult byte."""
+    for normals in (False, True):
+        s = irl.HostScene.import_file(irl.REPO_ROOT / "assets" / "hdri_test.dae", load_normals=normals)
+        d = s.desc
+        d.set_image(200, 160); d.samples_per_pixel = 10
+        dev = irl.IpuScene(d)
+        got = s.init_ray_stream(); want = got.copy()
+        dev.run(got, irl.MODE_SHADOW_TRACE); ol.shadow_trace(d, want, 16)
+        assert_streams_identical(got, want, f"hdri_test.dae shadow trace, normals={normals}")
+        got = s.init_ray_stream(); want = got.copy()
+        dev.run(got, irl.MODE_PATH_TRACE); ol.path_trace_pixel_rng(d, want, 16)
+        assert_streams_identical(got, want, f"hdri_test.dae path trace, normals={normals}")
+        assert (got["h"]["flags"] & irl.FLAG_ESCAPED).mean() > 0.1
+        dev.close()
+
+
 @pytest.mark.parametrize("maxlen,roulette,aa,seed", [(1, 3, 0.25, 1442), (3, 0, 0.0, 7), (10, 1, 1.5, 2**40 + 3), (0, 3, 0.25, 1)])
 def test_path_trace_parameter_edges(scenes, maxlen, roulette, aa, seed):
     s = scenes["box"]
@@ -126,6 +144,21 @@ def test_path_trace_parameter_edges(scenes, maxlen, roulette, aa, seed):
     assert_streams_identical(got, want, f"path-trace maxlen={maxlen} roulette={roulette} aa={aa}")
     dev.close()
     d.max_path_length, d.roulette_start_depth, d.anti_alias_scale, d.rng_seed = 10, 3, 0.25, 1442
+
+
+def test_scene_with_non_finite_node_bounds_is_rejected(scenes):
+    """The box test's min/max form assumes finite slab products; a BVH whose node bounds are NaN / inf is a malformed
+    scene and mi_scene_create says so instead of rendering it."""
+    s = scenes["box-simple"]
+    nodes = s.nodes.copy()
+    d = irl.SceneDesc.from_buffer_copy(s.desc)
+    for field, value in (("min_x", np.nan), ("min_z", np.inf), ("dy", 0x7C00)):
+        bad = nodes.copy(); bad[field][3] = value
+        d.bvh_nodes = bad.ctypes.data
+        with pytest.raises(irl.RaylibError, match="not finite"):
+            irl.IpuScene(d)
+    d.bvh_nodes = nodes.ctypes.data
+    irl.IpuScene(d).close()
 
 
 def test_ragged_empty_and_crop(scenes):

@@ -114,6 +114,26 @@ def test_collada_import_config3_scene():
     assert b"No camera found" in irl.host_lib().mi_host_last_error()       # scene_utils.cpp:177-180
 
 
+def test_collada_import_nif_demo_scene():
+    """assets/hdri_test.dae, the reference's NIF demo geometry (6 meshes / 5 656 triangles, an open
+    scene lit by the environment only): mesh and triangle inventory, one BVH leaf per triangle, the reference's material
+    heuristics (src/scene_utils.cpp:236-289: glass by name -> refractive, reflectivity -> specular, no emitters), a camera
+    in the file, everything in front of it, optional per-vertex normals."""
+    s = irl.HostScene.import_file(ROOT / "assets" / "hdri_test.dae", load_normals=False)
+    d = s.desc
+    assert (d.num_meshes, d.num_tris, d.num_geometry, d.num_nodes) == (6, 5656, 6, 2 * 5656 - 1)
+    assert [int(t) for t in s.mesh_info["numTriangles"]] == [480, 1152, 12, 12, 3936, 64]
+    assert d.num_normals == 0 and d.num_spheres == 0 and d.num_discs == 0
+    m = s.materials
+    assert d.num_materials == 5 and not m["emissive"].any() and sorted(int(x) for x in m["type"]) == [0, 1, 1, 2, 2]
+    assert [int(x) for x in s.mat_ids[:6]] == [0, 1, 2, 3, 3, 4]
+    assert 0.5 < d.fov_radians < 1.5 and s.verts["z"].max() < 0
+    leaves = s.nodes[s.nodes["geomID"] != irl.INVALID_GEOM]
+    assert leaves.size == 5656 and d.max_leaf_depth >= 13
+    n = irl.HostScene.import_file(ROOT / "assets" / "hdri_test.dae", load_normals=True)
+    assert n.desc.num_tris == 5656 and n.desc.num_normals == n.desc.num_verts > 0
+
+
 def test_monkey_scene_config5():
     s = irl.HostScene.builtin("monkey")
     assert (s.desc.num_meshes, s.desc.num_tris, s.desc.num_spheres, s.desc.num_discs) == (2, 4000, 0, 0)
@@ -144,6 +164,54 @@ def test_host_error_behaviour():
     assert b"Invalid scene selection" in lib.mi_host_last_error()
     assert lib.mi_host_scene_builtin(b"box", b"/nonexistent/file.glb", C.byref(h)) == 4   # MI_ERR_IO
     assert lib.mi_host_scene_builtin(None, None, C.byref(h)) == 1
+
+
+def _tiny_glb(path, nodes, indices, n_verts=3, normals=None):
+    """A minimal glTF-binary file: one mesh, POSITION (+ optional NORMAL) and u16 indices; `nodes` is the JSON node list."""
+    import json, struct
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0]][:n_verts], np.float32).tobytes()
+    idx = np.array(indices, np.uint16).tobytes()
+    idx += b"\0" * (-len(idx) % 4)
+    views = [{"buffer": 0, "byteOffset": 0, "byteLength": len(pos)}, {"buffer": 0, "byteOffset": len(pos), "byteLength": len(idx)}]
+    accessors = [{"bufferView": 0, "componentType": 5126, "count": n_verts, "type": "VEC3"}, {"bufferView": 1, "componentType": 5123, "count": len(indices), "type": "SCALAR"}]
+    attrs = {"POSITION": 0}
+    blob = pos + idx
+    if normals is not None:
+        nb = np.array(normals, np.float32).tobytes()
+        views.append({"buffer": 0, "byteOffset": len(blob), "byteLength": len(nb)})
+        accessors.append({"bufferView": 2, "componentType": 5126, "count": len(normals), "type": "VEC3"})
+        attrs["NORMAL"] = 2
+        blob += nb
+    doc = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}], "nodes": nodes, "meshes": [{"primitives": [{"attributes": attrs, "indices": 1}]}],
+           "buffers": [{"byteLength": len(blob)}], "bufferViews": views, "accessors": accessors}
+    js = json.dumps(doc).encode(); js += b" " * (-len(js) % 4)
+    body = struct.pack("<II", len(js), 0x4E4F534A) + js + struct.pack("<II", len(blob), 0x004E4942) + blob
+    path.write_bytes(struct.pack("<III", 0x46546C67, 2, 12 + len(body)) + body)
+    return path
+
+
+def test_glb_importer_rejects_malformed_files(tmp_path):
+    """Input hardening of the glTF-binary reader: indices are range-checked against the vertex count before they are
+    narrowed to the reference's 16-bit Triangle indices (include/Primitives.hpp:21-25), a node that is its own
+    ancestor is an error instead of endless recursion, and a NORMAL accessor must match POSITION."""
+    lib = irl.host_lib()
+
+    def load(path, normals=False):
+        h = C.c_void_p()
+        rc = lib.mi_host_scene_builtin(b"box", str(path).encode(), C.byref(h)) if not normals else lib.mi_host_scene_builtin(b"monkey", str(path).encode(), C.byref(h))
+        msg = lib.mi_host_last_error().decode()
+        if rc == 0:
+            lib.mi_host_scene_destroy(h)
+        return rc, msg
+
+    ok = _tiny_glb(tmp_path / "ok.glb", [{"mesh": 0}], [0, 1, 2])
+    assert load(ok)[0] == 0
+    rc, msg = load(_tiny_glb(tmp_path / "idx.glb", [{"mesh": 0}], [0, 1, 3]))
+    assert rc != 0 and "out of range" in msg
+    rc, msg = load(_tiny_glb(tmp_path / "cycle.glb", [{"children": [1]}, {"mesh": 0, "children": [0]}], [0, 1, 2]))
+    assert rc != 0 and "cycle" in msg
+    rc, msg = load(_tiny_glb(tmp_path / "child.glb", [{"mesh": 0, "children": [7]}], [0, 1, 2]))
+    assert rc != 0 and "out of range" in msg
 
 
 def test_bvh_builder_generic_boxes():

@@ -133,6 +133,88 @@ def test_reference_struct_layout():
     assert irl.HIT.fields["geomID"][1] == 60 and irl.HIT.fields["flags"][1] == 62
 
 
+def test_reference_material_layout_defaults_and_constructor():
+    """include/Material.hpp:8-35 compiled from the reference: size, field offsets, the Type values, the default ior
+    1.52 and `emissive = emission.isNonZero()`. mi_material (include/mi_raylib.h), the numpy dtype the tests use and
+    the materials of the built-in scenes must have exactly those bytes (the three bytes after `emissive` are padding
+    the reference never writes; they are masked)."""
+    size, align, o_albedo, o_ior, o_emission, o_type, o_emissive, diffuse, specular, refractive, type_size = [int(x) for x in GOLD["material_layout"]]
+    assert (size, align, type_size) == (36, 4, 4) and (diffuse, specular, refractive) == (0, 1, 2)
+    M = irl.MATERIAL
+    assert M.itemsize == size
+    assert (M.fields["albedo"][1], M.fields["ior"][1], M.fields["emission"][1], M.fields["type"][1], M.fields["emissive"][1]) == (o_albedo, o_ior, o_emission, o_type, o_emissive)
+    dflt = GOLD["material_default"].view(M)[0]
+    assert dflt["ior"] == np.float32(1.52) and dflt["type"] == 0 and dflt["emissive"] == 0 and not np.any(GOLD["material_default"][:12]) and not np.any(GOLD["material_default"][16:28])
+    assert list(GOLD["material_default_init"][33:]) == [False] * 3 and GOLD["material_default_init"][:33].all()      # bytes 33..35 are padding
+    # Material(albedo, emission, type): the product's own constructor path (scene_builtin.cpp makeMaterial through
+    # HostScene.from_arrays would need a scene; the numpy restatement below is what every test scene is built with)
+    for row, want, init in zip(GOLD["material_in"], GOLD["material_bytes"], GOLD["material_init"]):
+        m = np.zeros(1, M)
+        m["albedo"] = tuple(row[:3]); m["emission"] = tuple(row[3:6]); m["type"] = int(row[6]); m["ior"] = 1.52
+        m["emissive"] = 1 if np.any(row[3:6] != 0) else 0                                            # isNonZero: -0.0 counts as zero, 1e-30 does not
+        assert np.array_equal(m.view(np.uint8)[init], want[init]), row
+    # the built-in scenes' material tables are such objects: emissive <=> emission != 0, ior 1.52, types 0..2
+    for name in ("box", "spheres", "monkey"):
+        hs = irl.HostScene.builtin(name)               # (the arrays are views into the host scene: keep it alive)
+        mats = hs.materials
+        assert mats.itemsize == size and np.all(mats["ior"] == np.float32(1.52)) and set(np.unique(mats["type"])) <= {0, 1, 2}
+        em = np.stack([mats["emission"][k] for k in "xyz"], 1)
+        assert np.array_equal(mats["emissive"] != 0, np.any(em != 0, axis=1))
+    assert np.array_equal(GOLD["nonzero_out"], [0, 0, 1, 1, 1])
+
+
+def test_reference_constructors_and_hit_constants(o):
+    """Ray(o, d), HitRecord(o, d), TraceResult(hit, uv), PixelCoord() and the HitRecord constants
+    (include/embree_utils/geometry.hpp:199-259) compiled from the reference, against the records the product's host
+    code (mi_init_ray_stream) and the oracle (o_init_ray_stream) start every render from. HitRecord(o, d) does not
+    initialise `throughput` (geometry.hpp:236-242): those 12 bytes are excluded."""
+    assert [int(x) for x in GOLD["hit_constants"]] == [irl.FLAG_ERROR, irl.FLAG_ESCAPED, irl.INVALID_GEOM, irl.INVALID_PRIM] == [1, 2, 0xFFFF, 0xFFFFFFFF]
+    assert np.all(np.isneginf(GOLD["pixelcoord_default"]))
+    keep = np.ones(84, bool); keep[20 + 48:20 + 60] = False                    # TraceResult.h.throughput
+    for od, uv, rb, hb, tb in zip(GOLD["ctor_od"], GOLD["ctor_uv"], GOLD["ray_bytes"], GOLD["hit_bytes"], GOLD["trace_bytes"]):
+        t = np.zeros(1, irl.TRACE_RESULT)
+        t["u"], t["v"] = np.float32(uv[0]), np.float32(uv[1])                 # PixelCoord(u32, u32) converts to float
+        t["h"]["r"]["origin"] = tuple(od[:3]); t["h"]["r"]["direction"] = tuple(od[3:])
+        t["h"]["r"]["tMin"] = 0.0; t["h"]["r"]["tMax"] = np.inf
+        t["h"]["primID"] = irl.INVALID_PRIM; t["h"]["geomID"] = irl.INVALID_GEOM; t["h"]["flags"] = 0
+        t["h"]["normal"] = (0.0, 0.0, 1.0)
+        got = t.view(np.uint8).reshape(-1)
+        assert np.array_equal(got[keep], tb[keep])
+        assert np.array_equal(got[20:52], rb) and np.array_equal(got[20:84][keep[20:]], hb[keep[20:]])
+    # the records a render starts from: host library and oracle, every field but the camera direction / pixel
+    s = irl.HostScene.builtin("box-simple"); s.desc.set_image(24, 16)
+    a = s.init_ray_stream()
+    b = np.zeros(a.size, irl.TRACE_RESULT); o.o_init_ray_stream(C.byref(s.desc), b.ctypes.data)
+    assert a.tobytes() == b.tobytes()
+    ref = GOLD["trace_bytes"][0].view(irl.TRACE_RESULT)[0]
+    for rec in (a[0], a[-1]):
+        assert rec["h"]["primID"] == ref["h"]["primID"] and rec["h"]["geomID"] == ref["h"]["geomID"] and rec["h"]["flags"] == ref["h"]["flags"]
+        assert rec["h"]["normal"] == ref["h"]["normal"] and rec["h"]["r"]["tMin"] == ref["h"]["r"]["tMin"] and rec["h"]["r"]["tMax"] == ref["h"]["r"]["tMax"]
+        assert tuple(rec["rgb"]) == tuple(ref["rgb"]) == (0.0, 0.0, 0.0)
+
+
+def test_reference_permute_abs_and_bounds():
+    """Vec3fa::permute / abs and Bounds3d (geometry.hpp:126-197) compiled from the reference: permute(ix, iy, iz)
+    is (c[ix], c[iy], c[iz]) - the axis rotation the ray shear and the triangle test apply as
+    permute(kx, ky, kz) with kx = (kz + 1) % 3, ky = (kx + 1) % 3 (src/Primitives.cpp:5-22, src/Mesh.cpp:12-20),
+    which the kernels spell as selects (csrc/trace_kernels.hpp permute_kz); an empty Bounds3d is (+inf, -inf), union is
+    component-wise min / max, centroid is (max + min) * 0.5f."""
+    for v, outs, ab in zip(GOLD["permute_v"], GOLD["permute_out"], GOLD["abs_out"]):
+        for k in range(27):
+            assert np.array_equal(bits(outs[k]), bits(v[[k // 9, (k // 3) % 3, k % 3]]))
+        for kz in range(3):
+            kx = (kz + 1) % 3; ky = (kx + 1) % 3
+            r1, r2 = kz == 0, kz == 1                                     # permute_kz's selects
+            sel = np.array([v[1] if r1 else (v[2] if r2 else v[0]), v[2] if r1 else (v[0] if r2 else v[1]), v[0] if r1 else (v[1] if r2 else v[2])], np.float32)
+            assert np.array_equal(bits(sel), bits(outs[kx * 9 + ky * 3 + kz]))
+        assert np.array_equal(bits(ab), bits(np.abs(v)))
+    assert np.array_equal(GOLD["bounds_default"], np.array([np.inf] * 3 + [-np.inf] * 3, np.float32))
+    lo, hi = GOLD["bounds_lo"], GOLD["bounds_hi"]
+    umin = np.minimum(lo[:, 0], lo[:, 1]); umax = np.maximum(hi[:, 0], hi[:, 1])
+    assert np.array_equal(bits(GOLD["bounds_union"][:, :3]), bits(umin)) and np.array_equal(bits(GOLD["bounds_union"][:, 3:6]), bits(umax))
+    assert np.array_equal(bits(GOLD["bounds_union"][:, 6:]), bits((umax + umin) * np.float32(0.5)))
+
+
 @pytest.mark.skipif(ol.ref_lib() is None, reason="oracle/_ref only exists where /root/reference was")
 def test_oracle_against_live_reference_dense(o):
     r = ol.ref_lib()
