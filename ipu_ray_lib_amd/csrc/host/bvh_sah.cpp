@@ -3,16 +3,20 @@
 // The reference drives Embree's rtcBuildBVH (branching factor 2, one primitive per leaf, SAH;
 // include/embree_utils/bvh.hpp:47-69) and flattens the pointer tree depth-first
 // (src/CompactBvhBuild.cpp:34-56). Embree is not available here and its tree topology is not
-// part of the format, so this is an own full-sweep SAH builder; what IS contractual and
-// reproduced exactly is the node encoding (src/CompactBvhBuild.cpp:5-32):
+// part of the format, so this is an own full-sweep SAH builder followed by an insertion-based
+// optimisation of the tree (below); what IS contractual and reproduced exactly is the node
+// encoding (src/CompactBvhBuild.cpp:5-32):
 //   * node i's first child is node i+1, the second child index is stored in the node;
 //   * interior nodes carry geomID 0xFFFF and the union of their children's boxes;
 //   * extents are stored as binary16 rounded UP (precision_utils.hpp:39-47), and an extent
 //     above 65504 is an error;
 //   * maxDepth counts levels with the root at depth 1 and bounds the traversal stack.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <numeric>
+#include <queue>
 #include <stdexcept>
 
 #include "scene_types.hpp"
@@ -95,6 +99,100 @@ struct Builder {
   }
 };
 
+// ---- tree optimisation by reinsertion ---------------------------------------------------------------------------
+// The sweep builder is greedy, top down. What a ray pays during traversal is one box test per child of every interior
+// node whose box it hits, i.e. (for uniformly distributed rays) the sum of the interior nodes' surface areas. That sum
+// is lowered after the build by taking subtrees out of the tree and putting each back at the position that increases
+// it least (Bittner, Hapala, Havran: "Fast insertion-based optimization of bounding volume hierarchies", 2013): a
+// node X is removed together with its parent (the sibling takes the parent's place), the best new sibling Y is found
+// by branch and bound over the induced area increase of Y's ancestors, and the freed parent becomes the common
+// parent of X and Y. The node format, the one-primitive-per-leaf rule and the depth-first layout are untouched; only
+// the topology - which the reference leaves to Embree and is not part of its format - changes.
+struct Reinserter {
+  std::vector<TreeNode>& t;
+  std::vector<int> parent;
+  int root;
+
+  Reinserter(std::vector<TreeNode>& tree, int r) : t(tree), parent(tree.size(), -1), root(r) {
+    for (int i = 0; i < (int)t.size(); ++i)
+      for (int c : t[i].child) if (c >= 0) parent[c] = i;
+  }
+  static Bounds merged(const Bounds& a, const Bounds& b) { Bounds u = a; u.grow(b); return u; }
+  void refitUp(int n) {
+    for (; n >= 0; n = parent[n]) t[n].box = merged(t[t[n].child[0]].box, t[t[n].child[1]].box);
+  }
+  double interiorArea() const {
+    double a = 0;
+    for (const TreeNode& n : t) if (n.prim < 0) a += halfArea(n.box);
+    return a;
+  }
+  // one reinsertion attempt of subtree x; returns the change of the interior-area sum (<= 0 when it moved)
+  bool reinsert(int x) {
+    const int p = parent[x];
+    if (p < 0 || parent[p] < 0) return false;                 // the root and its children stay
+    const int g = parent[p];
+    const int s = t[p].child[0] == x ? t[p].child[1] : t[p].child[0];
+    // take x and p out: s takes p's place
+    t[g].child[t[g].child[0] == p ? 0 : 1] = s;
+    parent[s] = g;
+    const double before = halfArea(t[p].box);
+    std::vector<std::pair<int, Bounds>> saved;                // ancestors' boxes, to undo cheaply
+    for (int a = g; a >= 0; a = parent[a]) { saved.emplace_back(a, t[a].box); t[a].box = merged(t[t[a].child[0]].box, t[t[a].child[1]].box); }
+    double removedGain = before;
+    for (auto& sv : saved) removedGain += halfArea(sv.second) - halfArea(t[sv.first].box);
+    // branch and bound for the best sibling y
+    const Bounds& xb = t[x].box;
+    const double xArea = halfArea(xb);
+    struct Cand { double induced; int node; bool operator<(const Cand& o) const { return induced > o.induced; } };
+    std::priority_queue<Cand> q;
+    q.push({0.0, root});
+    double bestCost = std::numeric_limits<double>::infinity();
+    int best = -1;
+    while (!q.empty()) {
+      const Cand c = q.top(); q.pop();
+      if (c.induced + xArea >= bestCost) break;
+      const double direct = halfArea(merged(t[c.node].box, xb));
+      const double total = c.induced + direct;
+      if (total < bestCost) { bestCost = total; best = c.node; }
+      if (t[c.node].prim < 0) {
+        const double childInduced = total - halfArea(t[c.node].box);
+        if (childInduced + xArea < bestCost) { q.push({childInduced, t[c.node].child[0]}); q.push({childInduced, t[c.node].child[1]}); }
+      }
+    }
+    if (best < 0 || bestCost >= removedGain - 1e-12 * removedGain) {
+      // no better place: put everything back
+      t[g].child[t[g].child[0] == s ? 0 : 1] = p;
+      parent[p] = g; parent[s] = p;
+      for (auto& sv : saved) t[sv.first].box = sv.second;
+      return false;
+    }
+    // p becomes the parent of (best, x) where best stood
+    const int bp = parent[best];
+    if (bp >= 0) t[bp].child[t[bp].child[0] == best ? 0 : 1] = p; else root = p;
+    parent[p] = bp;
+    t[p].child[0] = best; t[p].child[1] = x;
+    parent[best] = p; parent[x] = p;
+    refitUp(p);
+    return true;
+  }
+  int run(int passes) {
+    int moved = 0;
+    for (int pass = 0; pass < passes; ++pass) {
+      std::vector<int> order;
+      for (int i = 0; i < (int)t.size(); ++i) if (i != root) order.push_back(i);
+      // largest boxes first: they are the ones whose misplacement costs most
+      std::vector<double> area(t.size());
+      for (int i : order) area[i] = halfArea(t[i].box);
+      std::sort(order.begin(), order.end(), [&](int a, int b) { return area[a] != area[b] ? area[a] > area[b] : a < b; });
+      int movedPass = 0;
+      for (int x : order) if (reinsert(x)) ++movedPass;
+      moved += movedPass;
+      if (movedPass == 0) break;
+    }
+    return moved;
+  }
+};
+
 mi_bvh_node toCompact(const TreeNode& t, const std::vector<BuildPrim>& prims) {
   mi_bvh_node c;
   c.min_x = t.box.lo.x; c.min_y = t.box.lo.y; c.min_z = t.box.lo.z;
@@ -129,7 +227,21 @@ void buildCompactBvh(const std::vector<BuildPrim>& prims, std::vector<mi_bvh_nod
   Builder b(prims);
   std::vector<uint32_t> ids(prims.size());
   std::iota(ids.begin(), ids.end(), 0u);
-  const int root = b.build(ids, 0, ids.size());
+  int root = b.build(ids, 0, ids.size());
+  {
+    // MI_BVH_REINSERT=<passes> overrides the default of 4 (0 = the plain sweep tree). Measured with the oracle's
+    // counters, 160x160 x 8 spp: box scene 21.08 -> 18.85 box tests and 2.55 -> 2.35 primitive tests per cast,
+    // test_scene.dae 30.9 -> 28.0 and 3.43 -> 3.22 (converged after 3 passes).
+    const char* e = std::getenv("MI_BVH_REINSERT");
+    const int passes = e ? std::atoi(e) : 4;
+    if (passes > 0 && prims.size() > 2) {
+      Reinserter r(b.tree, root);
+      const double a0 = r.interiorArea();
+      const int moved = r.run(passes);
+      root = r.root;
+      if (std::getenv("MI_BVH_VERBOSE")) std::fprintf(stderr, "[bvh] reinsertion: %d moves, interior area %.6g -> %.6g\n", moved, a0, r.interiorArea());
+    }
+  }
   nodes.reserve(2 * prims.size() - 1);
   flatten(b, root, nodes, 1, maxDepth);
 }
