@@ -1,31 +1,106 @@
 #!/usr/bin/env python3
-"""Copies the outputs of tools/prof_k1w.sh + `python bench.py > gpurun_out/bench_final.json` from gpurun_out/ into
-profiles/ (kernel stats, one PMC row per counter, the HBM summary bench.py reads, the bench line)."""
+"""Turns the outputs of tools/prof_r02.sh (gpurun_out/prof_r02/) into the files under profiles/:
+  r02_<set>_kernel_stats.csv     rocprofv3 --kernel-trace --stats summary (sets c2, c3, spp16, nif, c5)
+  r02_<set>_pmc.csv              one row per counter of the set's dominant kernel (mean over the timed launches)
+  r02_pmc_summary.json           what bench.py quotes as offline-measured (HBM bytes per launch, VALU figures)
+  r02_bench.json                 the un-profiled bench line of the same build
+  r02_config5.json               config 5 at 1440^2 x 4000 spp on one GPU + the kernel shares of a profiled 512-spp run"""
 import csv, glob, json, shutil
 from pathlib import Path
 R = Path(__file__).resolve().parent.parent
-shutil.copy(R / "gpurun_out/k1wprof/stats/k1w_kernel_stats.csv", R / "profiles/r01_final_kernel_stats.csv")
-d = json.loads((R / "gpurun_out/bench_final.json").read_text())
-(R / "profiles/r01_final_bench.json").write_text(json.dumps(d, indent=1))
-rows, hdr, agg = [], None, {}
-for f in sorted(glob.glob(str(R / "gpurun_out/k1wprof/g*/**/*counter_collection.csv"), recursive=True)):
-    seen = set()
-    for row in csv.DictReader(open(f)):
-        hdr = list(row.keys())
-        if "path_trace_wavefront_kernel<false" not in row["Kernel_Name"]:
-            continue
-        if row["Counter_Name"] not in seen:
-            seen.add(row["Counter_Name"]); rows.append(row)
-        if row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
-            agg.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-rows.sort(key=lambda r: r["Counter_Name"])
-with open(R / "profiles/r01_final_pmc.csv", "w", newline="") as o:
-    w = csv.DictWriter(o, fieldnames=hdr); w.writeheader(); w.writerows(rows)
-fs = sum(agg["FETCH_SIZE"]) / len(agg["FETCH_SIZE"]); ws = sum(agg["WRITE_SIZE"]) / len(agg["WRITE_SIZE"])
-p = R / "profiles/r01_pmc_hbm_summary.json"
-s = json.loads(p.read_text()); s["FETCH_SIZE_KB"] = fs; s["WRITE_SIZE_KB"] = ws; s["hbm_bytes_per_launch"] = int((2 * fs + ws) * 1024)
-p.write_text(json.dumps(s, indent=1))
-stats = list(csv.DictReader(open(R / "profiles/r01_final_kernel_stats.csv")))
-k = next(r for r in stats if "path_trace_wavefront_kernel<false" in r["Name"])
-print(f"bench {d['value']:.4e} casts/s, {d['ms_per_step']:.2f} ms/step; rocprofv3 stats {float(k['AverageNs']) / 1e6:.2f} ms avg over {k['Calls']} launches; "
-      f"FETCH {fs:.0f} KB WRITE {ws:.0f} KB -> {s['hbm_bytes_per_launch'] / 1e9:.2f} GB per launch; {len(rows)} PMC rows")
+SRC = R / "gpurun_out" / "prof_r02"
+DST = R / "profiles"
+CUS, SIMDS = 256, 1024
+
+
+def pmc(tag, kernel_substr):
+    agg = {}
+    for f in sorted(glob.glob(str(SRC / tag / "g*" / "**" / "*counter_collection.csv"), recursive=True)):
+        for row in csv.DictReader(open(f)):
+            if kernel_substr in row["Kernel_Name"]:
+                agg.setdefault(row["Counter_Name"], []).append((float(row["Counter_Value"]), row))
+    out = {}
+    rows = []
+    for name, vals in sorted(agg.items()):
+        use = vals[1:] if len(vals) > 1 else vals          # the first launch of a run is the warm-up
+        mean = sum(v for v, _ in use) / len(use)
+        out[name] = mean
+        r = dict(use[-1][1]); r["Counter_Value"] = f"{mean:.6f}"; r["Launches_Averaged"] = len(use)
+        rows.append(r)
+    if rows:
+        with open(DST / f"r02_{tag}_pmc.csv", "w", newline="") as o:
+            w = csv.DictWriter(o, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
+    return out
+
+
+def stats(tag):
+    src = SRC / tag / "stats"
+    f = next(iter(glob.glob(str(src / "**" / "*kernel_stats.csv"), recursive=True)), None)
+    if not f:
+        return []
+    shutil.copy(f, DST / f"r02_{tag}_kernel_stats.csv")
+    return list(csv.DictReader(open(f)))
+
+
+bench = json.loads((SRC / "bench.json").read_text())
+(DST / "r02_bench.json").write_text(json.dumps(bench, indent=1))
+report = []
+for tag, kern in (("c2", "path_trace_wavefront_kernel<false"), ("c3", "path_trace_wavefront_kernel<false"), ("spp16", "path_trace_wavefront_kernel<false"), ("nif", "nif_mlp_kernel")):
+    c = pmc(tag, kern)
+    st = stats(tag)
+    k = next((r for r in st if kern.split("<")[0] in r["Name"] and ("<false" in r["Name"] or "nif" in r["Name"])), None)
+    line = f"{tag}: "
+    if k:
+        line += f"{kern.split('<')[0]} avg {float(k['AverageNs']) / 1e6:.3f} ms over {k['Calls']} launches ({k['Percentage']} % of GPU time); "
+    if "SQ_INSTS_VALU" in c and "GRBM_GUI_ACTIVE" in c:
+        cycles = c["GRBM_GUI_ACTIVE"] / 8.0                                  # the counter sums the 8 XCDs
+        line += f"VALU busy {c['SQ_INSTS_VALU'] * 2 / (SIMDS * cycles):.3f}, "
+        if "SQ_THREAD_CYCLES_VALU" in c:
+            line += f"lanes active {c['SQ_THREAD_CYCLES_VALU'] / (64 * c['SQ_ACTIVE_INST_VALU']):.3f}, "
+        if "TA_TA_BUSY_sum" in c:
+            line += f"TA busy {c['TA_TA_BUSY_sum'] / CUS / cycles:.3f}, "
+        if "SQ_WAIT_INST_ANY" in c:
+            line += f"waiting {c['SQ_WAIT_INST_ANY'] / c['SQ_WAVE_CYCLES']:.3f}, "
+    if "FETCH_SIZE" in c:
+        line += f"HBM {(2 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024 / 1e9:.2f} GB per launch"
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+        cycles = c["GRBM_GUI_ACTIVE"] / 8.0
+        line += f"MFMA busy {c['SQ_VALU_MFMA_BUSY_CYCLES'] / (SIMDS * cycles):.3f}, waiting {c['SQ_WAIT_INST_ANY'] / c['SQ_WAVE_CYCLES']:.3f}, shader clock during the launch {cycles / (float(k['AverageNs']) * 1e-9) / 1e9:.2f} GHz"
+    report.append(line)
+    if tag == "c2":
+        cycles = c["GRBM_GUI_ACTIVE"] / 8.0
+        casts = bench["value"] * bench["ms_per_step"] * 1e-3
+        summary = {
+            "workload": ["box", 1440, 1440, 1000, 1],
+            "kernel": "path_trace_wavefront_kernel<false,false,256,5> (+ segment_combine_kernel, not included)",
+            "source": "rocprofv3 --pmc, one group per pass (tools/prof_r02.sh: python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras; profiles/r02_c2_pmc.csv), mean over the timed launches of a pass",
+            "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c["WRITE_SIZE"],
+            "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE counts 128-B requests at 64 B -> doubled; WRITE_SIZE exact. The ray-record reads are 20 B out of every 84-B record, an access width the guide calls uncalibrated, so the doubled figure is an upper bound.",
+            "hbm_bytes_per_launch": int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024),
+            "algorithmic_hbm_bytes_per_launch": int(2073600 * (84 + 84 + 16 * (84 + 12) + 16 * 12)),
+            "valu": {"insts_per_cast": c["SQ_INSTS_VALU"] / casts, "salu_insts_per_cast": c["SQ_INSTS_SALU"] / casts,
+                     "busy": c["SQ_INSTS_VALU"] * 2 / (SIMDS * cycles), "lanes_active": c["SQ_THREAD_CYCLES_VALU"] / (64 * c["SQ_ACTIVE_INST_VALU"]),
+                     "useful_lane_ops_frac": c["SQ_INSTS_VALU"] * 2 / (SIMDS * cycles) * c["SQ_THREAD_CYCLES_VALU"] / (64 * c["SQ_ACTIVE_INST_VALU"]),
+                     "ta_busy": c["TA_TA_BUSY_sum"] / CUS / cycles, "wave_cycles_waiting": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+                     "l1_hit_rate": 1 - c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"],
+                     "note": "a wave64 VALU instruction occupies a SIMD for 2 cycles (MI355X_MICROARCH.md): busy = SQ_INSTS_VALU x 2 / (1024 SIMDs x shader cycles); lanes_active = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)"},
+        }
+        (DST / "r02_pmc_summary.json").write_text(json.dumps(summary, indent=1))
+
+# config 5
+c5 = json.loads((SRC / "c5_full.json").read_text().strip().splitlines()[0])
+st = stats("c5")
+tot = sum(float(r["TotalDurationNs"]) for r in st) or 1.0
+shares = {r["Name"].split("(")[0][:60]: round(float(r["TotalDurationNs"]) / tot, 4) for r in st if float(r["TotalDurationNs"]) / tot > 0.002}
+mlp = next((r for r in st if "nif_mlp_kernel" in r["Name"]), None)
+c5["ms_per_frame_4000spp"] = c5["ms_per_sample"] * 4000
+c5["kernel_time_shares_512spp_profiled"] = shares
+if mlp:
+    c5["nif_mlp_share"] = round(float(mlp["TotalDurationNs"]) / tot, 4)
+c5["k3_mfma_frac_of_2.5PF"] = bench["nif"]["roofline"]["frac"]
+c5["note"] = "tools/bench_config5.py 4000 on one MI355X (device-resident stream, synthetic NIF weights of the reference's shape); shares from rocprofv3 --kernel-trace --stats of the same tool at 512 spp (profiles/r02_c5_kernel_stats.csv)"
+(DST / "r02_config5.json").write_text(json.dumps(c5, indent=1))
+report.append(f"c5: {c5['ms_per_sample']:.3f} ms per sample, {c5['ms_per_frame_4000spp'] / 1e3:.2f} s per 4000-spp frame; MLP share {c5.get('nif_mlp_share')}")
+report.append(f"bench: {bench['value']:.4e} casts/s, {bench['ms_per_step']:.2f} ms/step, parity {bench['parity_checked_pixels']} px / {bench['parity_mismatches']} mismatches")
+(DST / "r02_profile_summary.txt").write_text("\n".join(report) + "\n")
+print("\n".join(report))
