@@ -83,6 +83,7 @@ struct SceneOptions {
   PoolTune poolTune;               // MI_RAYLIB_POOL_TUNE / "pool_tune": leafAt,burst,retireAt,refillMin,shadeW,genW[,dbl,maxExtra,leafThenNode,prio]
   int poolWaves = 4;               // MI_RAYLIB_POOL_WAVES / "pool_waves": waves per workgroup of the path-pool kernel, 4 | 8 | 16 (400 | 800 | 1600 slots)
   int wavesPerSimd = 5;            // MI_RAYLIB_WAVES / "waves": 4 = the 108-VGPR build of the default kernel
+  bool specLeaf = false;           // MI_RAYLIB_SPEC / "spec": lanes walk on past ONE pending primitive test (trace_wavefront.hpp, SPEC)
   bool tiles = true;               // MI_RAYLIB_NO_TILES / "tiles": walk row-structured streams in 8x8 pixel tiles
   size_t segBudgetKb = (size_t)8 * 1024 * 1024;   // MI_RAYLIB_SEG_BUDGET_KB / "seg_budget_kb": partial-sum buffer budget per launch
   uint32_t nifSamplesPerLaunch = 0;               // MI_RAYLIB_NIF_SPL / "nif_spl": 0 = default (128, memory permitting)
@@ -100,20 +101,21 @@ struct SceneOptions {
       poolTune = {a, b, c ? c : 1, d ? d : 1, e, f, db ? db : 65, mx, ln, pr};
     }
     else if (key == "waves") wavesPerSimd = (v[0] == '4') ? 4 : 5;
+    else if (key == "spec") specLeaf = v[0] == '1';
     else if (key == "tiles") tiles = v[0] != '0';
     else if (key == "seg_budget_kb") segBudgetKb = std::max<size_t>((size_t)strtoull(v, nullptr, 10), 1);
     else if (key == "nif_spl") nifSamplesPerLaunch = (uint32_t)atoi(v);
     else if (key == "pin") pin = v[0] != '0';
     else if (key == "nif_shape") nifShape = (v[0] == 't') ? ((v[1] == '6') ? 1u : 2u) : 0u;
     else if (key == "tune") {      // leafAt,shadeAt,genAt[,burst,keep8,dbl,maxExtra,leafThenNode,prio]
-      unsigned a, b, c, dd = 48, k8 = 3, db = 4, mx = 5, ln = 1, pr = 1;
-      if (sscanf(v, "%u,%u,%u,%u,%u,%u,%u,%u,%u", &a, &b, &c, &dd, &k8, &db, &mx, &ln, &pr) < 3) return false;
-      tune = {a, b, c, dd, k8, db ? db : 65, mx, ln, pr};
+      unsigned a, b, c, dd = 48, k8 = 3, db = 4, mx = 5, ln = 1, pr = 1, lp = 40;
+      if (sscanf(v, "%u,%u,%u,%u,%u,%u,%u,%u,%u,%u", &a, &b, &c, &dd, &k8, &db, &mx, &ln, &pr, &lp) < 3) return false;
+      tune = {a, b, c, dd, k8, db ? db : 65, mx, ln, pr, lp ? lp : 1};
     } else return false;
     return true;
   }
   void fromEnvironment() {
-    static const char* const map[][2] = {{"MI_RAYLIB_FULL_STATS", "full_stats"}, {"MI_RAYLIB_KERNEL", "kernel"}, {"MI_RAYLIB_WAVES", "waves"},
+    static const char* const map[][2] = {{"MI_RAYLIB_FULL_STATS", "full_stats"}, {"MI_RAYLIB_KERNEL", "kernel"}, {"MI_RAYLIB_WAVES", "waves"}, {"MI_RAYLIB_SPEC", "spec"},
                                          {"MI_RAYLIB_SEG_BUDGET_KB", "seg_budget_kb"}, {"MI_RAYLIB_NIF_SPL", "nif_spl"}, {"MI_RAYLIB_PIN", "pin"},
                                          {"MI_RAYLIB_NIF_SHAPE", "nif_shape"}, {"MI_RAYLIB_TUNE", "tune"},
                                          {"MI_RAYLIB_POOL_TUNE", "pool_tune"}, {"MI_RAYLIB_POOL_WAVES", "pool_waves"}};
@@ -435,10 +437,12 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
     } else if (!STATS && S.opt.wavesPerSimd == 5) {
       // 96-VGPR build: 5 waves per SIMD (+4.6 % on the box scene; 6 waves = 80 VGPRs: -19 %, its spills land in LEAF/SHADE)
       const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 255) / 256, 256 * 8);
-      hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, 5>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
+      if (S.opt.specLeaf) hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, 5, true>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
+      else hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, 5>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
     } else {
       const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 255) / 256, 256 * 8);
-      hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
+      if (S.opt.specLeaf) hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, 4, true>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
+      else hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
     }
     if (segmented) hipLaunchKernelGGL(segment_combine_kernel, dim3((cnt + 255) / 256), dim3(256), 0, stream, d_rays, cnt, exs.segments, slot.d_segPart, segBase ? 1u : 0u);
   }

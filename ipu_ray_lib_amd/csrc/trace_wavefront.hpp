@@ -36,7 +36,8 @@ enum : uint32_t { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_GEN = 3, PH_FETCH =
 //   leafThenNode    a box test follows every LEAF turn at once
 //   prio     1: waves run their traversal turns at s_setprio 1 (short dependent steps win VALU arbitration over
 //            another wave's long SHADE/GEN blocks: +1 %), 0: no priorities
-struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, dbl = 4, maxExtra = 5, leafThenNode = 1, prio = 1; };
+//   leafP    (SPEC build) a LEAF turn also runs once this many lanes hold a pending primitive test
+struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, dbl = 4, maxExtra = 5, leafThenNode = 1, prio = 1, leafP = 40; };
 
 // Per-launch extras for renders with the NIF environment. The reference traces ONE sample, evaluates the
 // environment for the rays that escaped, adds it, and repeats (src/IpuScene.cpp:571-583). One sample per launch
@@ -67,7 +68,15 @@ struct WaveExtras {
   uint32_t segBase = 0;
 };
 
-template <bool STATS, bool LDS_NODES, int BLOCK, int WAVES_PER_SIMD = 4>
+// SPEC: a lane whose walk reaches a primitive whose box it hits does not wait for the LEAF turn: it notes the primitive
+// (pend1, found at node pend1Node) and walks on as if the test were going to leave the closest hit unchanged - which
+// is what the reference's walk does in that case. When the LEAF turn has run the test, either the guess was right
+// (no closer hit: the box tests made meanwhile used the right hit distance and stand) or the lane goes back to node
+// pend1Node + 1 with the new, closer hit and repeats the walk from there, exactly as the reference continues. A second
+// primitive found while the first is still pending makes the lane wait as before. Nothing is ever skipped or reordered
+// in what a path finally takes from the walk: only work that turns out to be unnecessary is added, in lanes that
+// would have idled.
+template <bool STATS, bool LDS_NODES, int BLOCK, int WAVES_PER_SIMD = 4, bool SPEC = false>
 __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? WAVES_PER_SIMD : 1) path_trace_wavefront_kernel(DeviceScene sc, mi_trace_result* rays, uint32_t n,
                                                                    uint32_t* workCounter, uint32_t ldsNodeCount, WaveTune tune, uint32_t tileStreamW, WaveExtras ex) {
   __shared__ float sinTbl[92];
@@ -96,6 +105,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
   // ---- lane state ----
   uint32_t ph = PH_FETCH;
   uint32_t pix = 0, sample = 0, bounce = 0, node = 0, pendLeaf = 0;
+  uint32_t pend1 = 0xFFFFFFFFu, pend1Node = 0, specNodes = 0;       // SPEC: the primitive test the lane has walked past, where it was found, box tests made since (STATS)
   float prow = 0.f, pcol = 0.f;
   Rng rng; rng.s0 = rng.s1 = 0;
   f3 color = mk(0, 0, 0), tp = mk(1, 1, 1);
@@ -235,6 +245,19 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
           }
           const bool boxHit = !(t0 > t1);
           const bool isLeaf = nd.geomID != 0xFFFFu;
+          if (SPEC) {
+            if (STATS) { if (pend1 != 0xFFFFFFFFu) { cs.nodes--; specNodes++; } }
+            if (boxHit && isLeaf) {
+              if (pend1 != 0xFFFFFFFFu) { pendLeaf = nd.link; ph = PH_LEAF; return false; }     // a second one: wait
+              pend1 = nd.link; pend1Node = node;                                                // the first one: walk on
+            }
+            node = (boxHit || isLeaf) ? node + 1 : nd.link;
+            if (node >= numNodes) {
+              if (pend1 != 0xFFFFFFFFu) { pendLeaf = 0xFFFFFFFFu; ph = PH_LEAF; } else ph = PH_SHADE;   // walked to the end with a test pending: wait for it
+              return false;
+            }
+            return true;
+          }
           pendLeaf = nd.link;          // only read while the lane is in PH_LEAF; assigned for every lane so that no merge copy is needed
           if (boxHit && isLeaf) {
             ph = PH_LEAF;
@@ -249,7 +272,8 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
       auto nodeStep = [&]() { if (ph == PH_NODE) (void)(anyExact ? nodeBodyT(std::true_type{}) : nodeBodyT(std::false_type{})); };
       for (;;) {
         const uint32_t stay = cN;
-        if (cN * 4u >= cL * tune.leafAt && cN > 0) {
+        const uint32_t cP = SPEC ? (uint32_t)__popcll(__ballot(pend1 != 0xFFFFFFFFu)) : 0u;
+        if (cN * 4u >= cL * tune.leafAt && cN > 0 && !(SPEC && cP >= tune.leafP)) {
           // NODE: one box test per lane. With many lanes in the walk two box tests run back to back before the wave
           // votes again (tune.dbl): a vote costs a ballot-popcount-branch chain whose latency the second test hides;
           // lanes that reached a leaf in the first simply sit the second out.
@@ -280,7 +304,45 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
           steps += extra;
         } else {
           // LEAF: one primitive test per lane
-          if (STATS) { itL++; lnL += cL; }
+          if (STATS) { itL++; lnL += SPEC ? cP : cL; }
+          if (SPEC) {
+            if (pend1 != 0xFFFFFFFFu) {
+              if (STATS) cs.leaves++;
+              const GLeaf L = sc.leaves[pend1];
+              float t, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+              bool cand;
+              const uint32_t kind = leaf_kind(L);
+              if (kind == LEAF_TRI) {
+                t = intersect_triangle(mk(L.f[0], L.f[1], L.f[2]), mk(L.f[3], L.f[4], L.f[5]), mk(L.f[6], L.f[7], L.f[8]), o, sh, b0, b1, b2);
+                cand = t > 0.f && t < kInf;
+              } else if (kind == LEAF_SPHERE) {
+                t = intersect_sphere(L, o, d, 0.f);
+                cand = true;
+              } else {
+                t = intersect_disc(L, o, d);
+                cand = true;
+              }
+              if (cand && t > 0.f && t < hit.t) {
+                // a closer hit: everything walked since is void, the walk resumes behind the primitive's node with it
+                hit.t = t; hit.leaf = pend1; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2;
+                node = pend1Node + 1;
+                pend1 = 0xFFFFFFFFu;
+                if (STATS) specNodes = 0;
+                ph = (node >= numNodes) ? PH_SHADE : PH_NODE;
+              } else {
+                // the guess was right: the box tests made meanwhile stand
+                if (STATS) { cs.nodes += specNodes; specNodes = 0; }
+                pend1 = 0xFFFFFFFFu;
+                if (ph == PH_LEAF) {
+                  if (pendLeaf != 0xFFFFFFFFu) {             // the second primitive becomes the pending one, the walk goes on
+                    pend1 = pendLeaf; pend1Node = node;
+                    node = node + 1;
+                    if (node >= numNodes) pendLeaf = 0xFFFFFFFFu; else ph = PH_NODE;
+                  } else ph = PH_SHADE;                      // the walk had already reached the end
+                }
+              }
+            }
+          } else
           if (ph == PH_LEAF) {
             if (STATS) cs.leaves++;
             const GLeaf L = sc.leaves[pendLeaf];

@@ -191,7 +191,7 @@ def campaign(budget=240.0, seed=1, scale=1, max_cases=None):
         batch = int(rng.integers(1, 4000)) if rng.random() < 0.25 else 0
         desc = (f"case {case} (seed {seed}): {what} {w}x{h} crop={crop} spp={spp} rngseed={d.rng_seed} aa={d.anti_alias_scale} "
                 f"len={d.max_path_length} roulette={d.roulette_start_depth} mode={mode} kernel={kernel} waves={waves} batch={batch}")
-        dev = irl.IpuScene(d).set_option("kernel", kernel).set_option("waves", waves)
+        dev = irl.IpuScene(d).set_option("kernel", kernel).set_option("waves", waves).set_option("spec", int(rng.integers(0, 2)))
         got = s.init_ray_stream()
         if rng.random() < 0.3:
             for k in "xyz":

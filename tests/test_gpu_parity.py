@@ -55,13 +55,16 @@ def test_shadow_trace_512_bit_exact(scenes, name):
     dev.close()
 
 
-def test_traversal_visits_exactly_the_reference_nodes(scenes):
+@pytest.mark.parametrize("spec", [0, 1])
+def test_traversal_visits_exactly_the_reference_nodes(scenes, spec):
     """Instrumented kernel variant: the number of BVH nodes visited and of primitive tests must equal the
-    oracle's stack traversal — i.e. the stackless walk reproduces the reference's visit order."""
+    oracle's stack traversal — i.e. the stackless walk reproduces the reference's visit order. With `spec` the
+    lanes walk on past one pending primitive test; box tests of walks that a closer hit voided are not counted,
+    the ones that stand are, and the totals must still be the reference's."""
     s = scenes["box"]
     s.desc.set_image(256, 256)
     s.desc.samples_per_pixel = 3
-    dev = irl.IpuScene(s.desc).set_option("full_stats", 1)
+    dev = irl.IpuScene(s.desc).set_option("full_stats", 1).set_option("spec", spec)
     got = s.init_ray_stream(); want = got.copy()
     dev.run(got, irl.MODE_SHADOW_TRACE)
     st = ol.shadow_trace(s.desc, want, 16)
@@ -81,16 +84,18 @@ def test_traversal_visits_exactly_the_reference_nodes(scenes):
 # path trace: rgb sums + last-sample hit records, per-pixel RNG streams
 # ------------------------------------------------------------------------------------------------------
 def _with_kernel(dev, kernel):
-    """kernel strings: "0" | "1" | "1w4" | "2" | "3" | "3p8" | "3p16" (variant + waves per SIMD / waves per pool workgroup)"""
+    """kernel strings: "0" | "1" | "1w4" | "1s" (speculative walk past a pending primitive test) | "2" | "3" | "3p8" | "3p16" (variant + waves per SIMD / waves per pool workgroup)"""
     dev.set_option("kernel", kernel[0])
     if kernel.endswith("w4"):
         dev.set_option("waves", 4)
+    if kernel.endswith("s"):
+        dev.set_option("spec", 1)
     if "p" in kernel:
         dev.set_option("pool_waves", kernel.split("p")[1])
     return dev
 
 
-@pytest.mark.parametrize("kernel", ["0", "1", "1w4", "2", "3", "3p8", "3p16"])
+@pytest.mark.parametrize("kernel", ["0", "1", "1w4", "1s", "2", "3", "3p8", "3p16"])
 @pytest.mark.parametrize("name,size,spp", [("box-simple", 128, 32), ("box", 160, 24), ("spheres", 128, 32)])
 def test_path_trace_bit_exact(scenes, name, size, spp, kernel):
     """kernel 0 = nested-loop kernel, 1 = phase-scheduled persistent kernel, 2 = the same with the BVH
@@ -649,7 +654,7 @@ def test_randomised_render_parameters_against_oracle(scenes):
         d.set_image(96, 64); d.anti_alias_scale = 0.25; d.max_path_length = 10; d.roulette_start_depth = 3; d.rng_seed = 1442
 
 
-@pytest.mark.parametrize("kernel,spp", [("0", 300), ("1", 300), ("2", 300), ("3", 300), ("0", 700), ("1", 700), ("2", 700), ("3", 700), ("3p16", 700)])
+@pytest.mark.parametrize("kernel,spp", [("0", 300), ("1", 300), ("2", 300), ("3", 300), ("1s", 300), ("0", 700), ("1", 700), ("1s", 700), ("2", 700), ("3", 700), ("3p16", 700)])
 def test_segmented_pixels_bit_exact(scenes, kernel, spp):
     """More samples per pixel than one segment holds: the pixel is traced as segments (about sixteen per pixel, 4 to 64
     samples long), each with its own RNG stream and partial rgb sum, added in segment order.
