@@ -44,7 +44,7 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 //   w6 (default) : 4 waves x 96 rays, two workgroups per CU; every packed weight fragment is fetched once per
 //                  workgroup and feeds 6 MFMAs. Needs 96 x stride x 2 B of LDS per workgroup.
 //   t6, t4       : 8 waves = 4 output-feature groups x 2 row groups of 96 / 64 rays (t4: any width up to 384).
-constexpr uint32_t kNifMaxLdsBytes = 160 * 1024 - 512;
+constexpr uint32_t kNifMaxLdsBytes = 160 * 1024 - 2048;   // dynamic LDS: what is left beside the static coordinate staging (2 x 192 floats)
 constexpr uint32_t kNifMaxLayers = 16;
 constexpr uint32_t kNifMaxTilesPerWave = 6;   // output-feature tiles (of 16) per wave: supports widths up to 384
 
@@ -125,7 +125,7 @@ struct NifDevice {
       if (l + 1 < numLayers && N > featBase) throw std::invalid_argument("NIF: internal width error");
       L.kSteps = (K + 31) / 32; L.nTiles = (((N + 15) / 16) + 3u) & ~3u; L.n = N; L.relu = relu[l] ? 1u : 0u;   // tiles padded to a multiple of 4: every wave owns nTiles/4 of them
       L.wOffset = (uint32_t)(packed.size() / 8);
-      for (uint32_t nt = 0; nt < L.nTiles; ++nt)
+      for (uint32_t nt = 0; nt < L.nTiles; ++nt) {
         for (uint32_t ks = 0; ks < L.kSteps; ++ks)
           for (uint32_t lane = 0; lane < 64; ++lane)
             for (uint32_t j = 0; j < 8; ++j) {
@@ -133,6 +133,18 @@ struct NifDevice {
               const float w = (k < K && n < N) ? kernels[l][(size_t)k * N + n] : 0.f;
               packed.push_back((_Float16)w);
             }
+        // fragment kSteps of the tile is not weights: lane l's 16 bytes are the four binary32 bias values of the
+        // output features its accumulator holds (16nt + 4(l>>4) + 0..3; zeros for a layer without bias). The weight
+        // pipeline's loads past the last k-step fetch it, so the bias arrives with the stream, for free.
+        for (uint32_t lane = 0; lane < 64; ++lane)
+          for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t n = nt * 16 + 4 * (lane >> 4) + q;
+            const float b = (biases && biases[l] && n < N) ? biases[l][n] : 0.f;
+            _Float16 two[2];
+            memcpy(two, &b, 4);
+            packed.push_back(two[0]); packed.push_back(two[1]);
+          }
+      }
       if (biases && biases[l]) { L.bOffset = (uint32_t)bias.size(); for (uint32_t n = 0; n < N; ++n) bias.push_back(biases[l][n]); for (uint32_t n = N; n < L.nTiles * 16; ++n) bias.push_back(0.f); }
       else L.bOffset = 0xFFFFFFFFu;
       width = N;
@@ -203,141 +215,166 @@ __global__ void __launch_bounds__(256) escaped_uv_kernel(const mi_trace_result* 
   if (escaped) index[base + __popcll(mask & ((1ull << lane) - 1ull))] = i;
 }
 
-// One dense layer for one wave: TN output-feature tiles (nt = ng + 4a) x MT ray tiles, fully unrolled, with its
-// own accumulators (so the register allocator never has to shuffle one layer shape's accumulators around
-// another's code), the next k-step's weight fragments in flight while the current ones feed the matrix cores,
-// and the bias / ReLU / binary16 store (or the decode + environment add for the last layer) as epilogue.
-template <uint32_t TN, uint32_t MT>
-__device__ __forceinline__ void nif_dense_layer(const NifParams& P, const NifLayerDesc& L, bool last, _Float16* X, uint32_t stride,
-                                                uint32_t rowBase, uint32_t ng, uint32_t lane, const h8* __restrict__ weights,
-                                                const float* __restrict__ bias, uint32_t row0, uint32_t total,
-                                                const uint32_t* __restrict__ idx, float* __restrict__ bgrOut, mi_trace_result* rays, bool scatter) {
+// A RUN of dense layers [l0, l1) for one wave: all of them give the wave TN output-feature tiles (nt = ng + 4a) x MT ray
+// tiles, fully unrolled, with their own accumulators. Per layer: the k-loop (the next k-steps' weight fragments in
+// flight while the current ones feed the matrix cores), then the epilogue (bias, ReLU, binary16 store - or, for the
+// network's final layer, decode + environment add).
+//
+// The loop is ROTATED: an iteration asks for its layer's k-step-0 fragments, THEN runs the previous layer's epilogue
+// (with its two barriers), THEN its own k-loop; the last layer's epilogue follows the loop. So the L2 latency of a
+// layer's first fragments is spent under the previous layer's epilogue instead of in front of its first MFMA, and no
+// register with a load in flight is carried around the loop's back edge: what IS carried are the accumulators and the
+// bias, ordinary values. (An earlier form issued the fragments at the END of the previous iteration; hipcc gave them
+// registers of their own and copied those into the k-loop's at the loop header - before they had landed.
+// tests/test_asm_pipeline_audit.py now follows the control flow and catches that.)
+// LAST: the run is the network's final layer alone (decode + global stores in its epilogue).
+template <uint32_t TN, uint32_t MT, bool LAST>
+__device__ __forceinline__ void nif_dense_layers(const NifParams& P, uint32_t l0, uint32_t l1, _Float16* X, uint32_t stride,
+                                                 uint32_t rowBase, uint32_t ng, uint32_t lane, const h8* __restrict__ weights,
+                                                 const float* __restrict__ bias, uint32_t row0, uint32_t total,
+                                                 const uint32_t* __restrict__ idx, float* __restrict__ bgrOut, mi_trace_result* rays, bool scatter) {
+  constexpr bool last = LAST;
   f4v acc[TN][MT];
-  // The accumulators start from the bias: it is the C operand of the first k-step's MFMAs (no zero fill, no bias add).
   f4v bv[TN];
-#pragma unroll
-  for (uint32_t a = 0; a < TN; ++a) {
-    bv[a] = (f4v){0.f, 0.f, 0.f, 0.f};
-    if (L.bOffset != 0xFFFFFFFFu) bv[a] = *reinterpret_cast<const f4v*>(&bias[L.bOffset + 16 * (ng + 4 * a) + 4 * (lane >> 4)]);
-  }
-  // Weight stream: three named fragment sets (k-steps 3j, 3j+1, 3j+2), each loaded two k-steps before it is used.
-  // hipcc sinks ordinary loads down to their first use here (it minimises live ranges at this register
-  // pressure: the .s showed "load, s_waitcnt vmcnt(0), mfma" every k-step), so the loads are inline asm, invisible
-  // to its scheduler, and their completion is counted by hand (cdna_hip_programming.md §5.7 form ii): loads return
-  // in order, every step issues exactly TN of them, so "all but the newest 2*TN have landed" is the set about to be
-  // used. Every destination is named "+v" in the wait, which keeps the consumers below it. The counts assume that
-  // nothing else joins the queue inside the k-loop: no compiler-issued global or scratch access may be in flight
-  // together with these loads (tests/test_asm_pipeline_audit.py checks the generated code for that, for copies or
-  // reuse of a destination before its wait, and for scratch).
-  h8 wA[TN], wB[TN], wC[TN];
-  const uint32_t kSteps = L.kSteps, kLast = kSteps - 1;
-  // Fragment (nt, ks) is 1 KiB at weights + wOffset + (nt*kSteps + ks)*64 (+ lane): a wave-uniform base, so the
-  // loads use the SGPR-base + VGPR-offset form and need ONE address VGPR (lane*16) for all of them.
+  const f4v zero4 = {0.f, 0.f, 0.f, 0.f};
+  // Fragment (nt, ks) is 1 KiB at weights + wOffset + (nt*(kSteps+1) + ks)*64 (+ lane): a wave-uniform base, so the
+  // loads use the SGPR-base + VGPR-offset form and need ONE address VGPR (lane*16) for all of them. Fragment kSteps of
+  // a tile is its bias (NifDevice::load).
   const uint32_t laneOff = lane * 16u;
   const uint32_t ngU = (uint32_t)__builtin_amdgcn_readfirstlane((int)ng);
-  auto loadW = [&](h8 (&w)[TN], uint32_t ks) {
-    ks = ks < kLast ? ks : kLast;                          // past the end: re-read the last fragment (keeps the count uniform)
+
+  // bias / ReLU / binary16 store of layer EL (or decode + environment add), between the two barriers that separate
+  // its k-loop's reads of X from these writes and these writes from the next k-loop's reads
+  auto epilogue = [&](const NifLayerDesc& EL) {
+    __syncthreads();   // every wave has read its inputs: X[.., 0..N) may be overwritten
 #pragma unroll
     for (uint32_t a = 0; a < TN; ++a) {
-      // all-scalar arithmetic (kernel arguments + ngU): the base is produced by SALU instructions, which a VMEM
-      // instruction may read without wait states (a v_readfirstlane result would need 5: §5.7 item 2)
-      // (32-bit offset arithmetic: there is no 64-bit scalar multiply, a 64-bit product would go through VALU registers;
-      // and the offset is pinned scalar with readfirstlane; the 64-bit add that consumes it is SALU)
-      const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)((((ngU + 4 * a) * kSteps) + ks) << 10));
-      const uint64_t sbase = (uint64_t)(uintptr_t)(weights + L.wOffset) + off;
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(w[a]) : "v"(laneOff), "s"(sbase));
-    }
-  };
-  auto landed = [&](h8 (&w)[TN], auto outstanding) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(outstanding)::value));
+      const uint32_t nt = ng + 4 * a;
+      if (16 * nt < EL.n) {
+        // D fragment: rows (= output features) 16nt + 4(lane>>4) + reg, column (= ray) 16m + (lane&15)
+        const uint32_t f0 = 16 * nt + 4 * (lane >> 4);
 #pragma unroll
-    for (uint32_t a = 0; a < TN; ++a) asm volatile("" : "+v"(w[a]));
-  };
-  // Activation fragments come from LDS through inline-asm reads as well, two in flight: hipcc otherwise emits
-  // "ds_read; s_waitcnt lgkmcnt(0); TN mfma" per ray tile, exposing the LDS latency MT times per k-step with only two
-  // waves per SIMD to cover it. Same hand-counted scheme: reads return in order, lgkmcnt(1) = all but the newest.
-  const uint32_t xAddr0 = (uint32_t)(uintptr_t)X + ((rowBase + (lane & 15)) * stride + L.inBase + 8 * (lane >> 4)) * 2u;
-  const uint32_t mStep = 16u * stride * 2u;
-  auto readX = [&](h8& x, uint32_t addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(x) : "v"(addr)); };
-  auto step = [&](const h8 (&w)[TN], uint32_t ks, auto first) {
-    // B fragment: X^T[k][ray] = X[ray = rowBase + 16m + (lane&15)][k = 32ks + 8(lane>>4) + j]
-    const uint32_t a0 = xAddr0 + 64u * ks;
-    h8 xb[3];                                   // three-deep ring: reads run two ray tiles ahead of the MFMAs
-    readX(xb[0], a0);
-    if (MT > 1) readX(xb[1], a0 + mStep);
+        for (uint32_t m = 0; m < MT; ++m) {
+          f4v y = acc[a][m] + bv[a];
+          const uint32_t r = rowBase + 16 * m + (lane & 15);
+          if (!last) {
+            // ReLU on the rounded halves (two packed max): rounding is monotone and keeps the sign, so
+            // max(round(y), 0) == round(max(y, 0))
+            h4 yh = {(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
+            if (EL.relu) yh = __builtin_elementwise_max(yh, (h4){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f});
+            *reinterpret_cast<h4*>(&X[r * stride + f0]) = yh;
+          } else if (nt == 0 && (lane >> 4) == 0 && row0 + r < total) {
+            // decode (NifModel.cpp:222-246): y*max + mean, exp for log-tonemapped models
+            if (EL.relu) {
 #pragma unroll
-    for (uint32_t m = 0; m < MT; ++m) {
-      if (m + 2 < MT) {
-        readX(xb[(m + 2) % 3], a0 + (m + 2) * mStep);
-        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xb[m % 3]));
-      } else if (m + 1 < MT) {
-        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(xb[m % 3]));
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xb[m % 3]));
-      }
+              for (int q = 0; q < 4; ++q) y[q] = y[q] > 0.f ? y[q] : 0.f;
+            }
+            float o[3];
 #pragma unroll
-      for (uint32_t a = 0; a < TN; ++a)
-        acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[a], xb[m % 3], decltype(first)::value ? bv[a] : acc[a][m], 0, 0, 0);
-    }
-  };
-  using TwoSets = std::integral_constant<int, 2 * TN>;
-  loadW(wA, 0);
-  loadW(wB, 1);
-  loadW(wC, 2); landed(wA, TwoSets{}); step(wA, 0, std::true_type{});
-  loadW(wA, 3); landed(wB, TwoSets{}); if (1 < kSteps) step(wB, 1, std::false_type{});
-  loadW(wB, 4); landed(wC, TwoSets{}); if (2 < kSteps) step(wC, 2, std::false_type{});
-  for (uint32_t ks = 3; ks < kSteps; ks += 3) {
-    loadW(wC, ks + 2); landed(wA, TwoSets{}); step(wA, ks, std::false_type{});
-    loadW(wA, ks + 3); landed(wB, TwoSets{}); if (ks + 1 < kSteps) step(wB, ks + 1, std::false_type{});
-    loadW(wB, ks + 4); landed(wC, TwoSets{}); if (ks + 2 < kSteps) step(wC, ks + 2, std::false_type{});
-  }
-  // drain: the two sets still in flight own their registers until they land
-  asm volatile("s_waitcnt vmcnt(0)");
-#pragma unroll
-  for (uint32_t a = 0; a < TN; ++a) { asm volatile("" : "+v"(wA[a])); asm volatile("" : "+v"(wB[a])); asm volatile("" : "+v"(wC[a])); }
-  __syncthreads();   // every wave has read its inputs: X[.., 0..N) may be overwritten
-#pragma unroll
-  for (uint32_t a = 0; a < TN; ++a) {
-    const uint32_t nt = ng + 4 * a;
-    if (16 * nt < L.n) {
-      // D fragment: rows (= output features) 16nt + 4(lane>>4) + reg, column (= ray) 16m + (lane&15)
-      const uint32_t f0 = 16 * nt + 4 * (lane >> 4);
-#pragma unroll
-      for (uint32_t m = 0; m < MT; ++m) {
-        f4v y = acc[a][m];
-        const uint32_t r = rowBase + 16 * m + (lane & 15);
-        if (!last) {
-          // ReLU on the rounded halves (two packed max): rounding is monotone and keeps the sign, so
-          // max(round(y), 0) == round(max(y, 0))
-          h4 yh = {(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
-          if (L.relu) yh = __builtin_elementwise_max(yh, (h4){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f});
-          *reinterpret_cast<h4*>(&X[r * stride + f0]) = yh;
-        } else if (nt == 0 && (lane >> 4) == 0 && row0 + r < total) {
-          // decode (NifModel.cpp:222-246): y*max + mean, exp for log-tonemapped models
-          if (L.relu) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) y[q] = y[q] > 0.f ? y[q] : 0.f;
-          }
-          float o[3];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            o[c] = y[c] * P.maxValue + P.mean[c];
-            if (P.logTonemap) o[c] = expf(o[c]);
-          }
-          const uint32_t row = row0 + r;
-          if (bgrOut) { const size_t dst = scatter ? (size_t)idx[row] : (size_t)row; bgrOut[3 * dst] = o[0]; bgrOut[3 * dst + 1] = o[1]; bgrOut[3 * dst + 2] = o[2]; }
-          if (rays) {
-            mi_trace_result* res = rays + (idx ? idx[row] : row);
-            const mi_vec3 tp = res->h.throughput;
-            res->rgb.x += tp.x * o[2];          // BGR -> RGB (codelets/TraceCodelets.cpp:376)
-            res->rgb.y += tp.y * o[1];
-            res->rgb.z += tp.z * o[0];
+            for (int c = 0; c < 3; ++c) {
+              o[c] = y[c] * P.maxValue + P.mean[c];
+              if (P.logTonemap) o[c] = expf(o[c]);
+            }
+            const uint32_t row = row0 + r;
+            if (bgrOut) { const size_t dst = scatter ? (size_t)idx[row] : (size_t)row; bgrOut[3 * dst] = o[0]; bgrOut[3 * dst + 1] = o[1]; bgrOut[3 * dst + 2] = o[2]; }
+            if (rays) {
+              mi_trace_result* res = rays + (idx ? idx[row] : row);
+              const mi_vec3 tp = res->h.throughput;
+              res->rgb.x += tp.x * o[2];          // BGR -> RGB (codelets/TraceCodelets.cpp:376)
+              res->rgb.y += tp.y * o[1];
+              res->rgb.z += tp.z * o[0];
+            }
           }
         }
       }
     }
+    __syncthreads();
+  };
+
+  for (uint32_t l = l0; l < l1; ++l) {
+    const NifLayerDesc L = P.layers[l];
+    const uint32_t kSteps = L.kSteps;
+    // Weight stream: three named fragment sets (k-steps 3j, 3j+1, 3j+2), each loaded two k-steps before it is used.
+    // hipcc sinks ordinary loads down to their first use here (it minimises live ranges at this register
+    // pressure: the .s showed "load, s_waitcnt vmcnt(0), mfma" every k-step), so the loads are inline asm, invisible
+    // to its scheduler, and their completion is counted by hand (cdna_hip_programming.md §5.7 form ii): loads return
+    // in order, every step issues exactly TN of them, so "all but the newest 2*TN have landed" is the set about to be
+    // used. Every destination is named in the wait ("; landed vN" for the audit), which keeps the consumers below it.
+    // The counts assume that only LOADS join the queue meanwhile (they return in order, so a younger one only makes a
+    // wait stricter); tests/test_asm_pipeline_audit.py checks the generated code for stores / atomics / scratch in
+    // flight together with these loads and for any touch of a destination before it has landed.
+    h8 wA[TN], wB[TN], wC[TN];
+    auto loadW = [&](h8 (&w)[TN], uint32_t ks) {
+      ks = ks < kSteps ? ks : kSteps;                        // past the end: the tile's bias fragment (keeps the count uniform)
+#pragma unroll
+      for (uint32_t a = 0; a < TN; ++a) {
+        // all-scalar arithmetic (kernel arguments + ngU): the base is produced by SALU instructions, which a VMEM
+        // instruction may read without wait states (a v_readfirstlane result would need 5: §5.7 item 2)
+        // (32-bit offset arithmetic: there is no 64-bit scalar multiply; the offset is pinned scalar with
+        // readfirstlane; the 64-bit add that consumes it is SALU)
+        const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)((((ngU + 4 * a) * (kSteps + 1)) + ks) << 10));
+        const uint64_t sbase = (uint64_t)(uintptr_t)(weights + L.wOffset) + off;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(w[a]) : "v"(laneOff), "s"(sbase));
+      }
+    };
+    auto landed = [&](h8 (&w)[TN], auto outstanding) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(outstanding)::value));
+#pragma unroll
+      for (uint32_t a = 0; a < TN; ++a) asm volatile("; landed %0" : "+v"(w[a]));
+    };
+    // k-step 0 first: it is in flight while the previous layer's epilogue runs
+    loadW(wA, 0);
+    if (l > l0) epilogue(P.layers[l - 1]);
+
+    // Activation fragments come from LDS through inline-asm reads as well, two in flight: hipcc otherwise emits
+    // "ds_read; s_waitcnt lgkmcnt(0); TN mfma" per ray tile, exposing the LDS latency MT times per k-step with only two
+    // waves per SIMD to cover it. Same hand-counted scheme: reads return in order, lgkmcnt(1) = all but the newest.
+    const uint32_t xAddr0 = (uint32_t)(uintptr_t)X + ((rowBase + (lane & 15)) * stride + L.inBase + 8 * (lane >> 4)) * 2u;
+    const uint32_t mStep = 16u * stride * 2u;
+    auto readX = [&](h8& x, uint32_t addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(x) : "v"(addr)); };
+    auto step = [&](const h8 (&w)[TN], uint32_t ks, auto first) {
+      // B fragment: X^T[k][ray] = X[ray = rowBase + 16m + (lane&15)][k = 32ks + 8(lane>>4) + j]
+      const uint32_t a0 = xAddr0 + 64u * ks;
+      h8 xb[3];                                   // three-deep ring: reads run two ray tiles ahead of the MFMAs
+      readX(xb[0], a0);
+      if (MT > 1) readX(xb[1], a0 + mStep);
+#pragma unroll
+      for (uint32_t m = 0; m < MT; ++m) {
+        if (m + 2 < MT) {
+          readX(xb[(m + 2) % 3], a0 + (m + 2) * mStep);
+          asm volatile("s_waitcnt lgkmcnt(2)\n\t; landed %0" : "+v"(xb[m % 3]));
+        } else if (m + 1 < MT) {
+          asm volatile("s_waitcnt lgkmcnt(1)\n\t; landed %0" : "+v"(xb[m % 3]));
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)\n\t; landed %0" : "+v"(xb[m % 3]));
+        }
+        // the first k-step's MFMAs take C = 0; the bias is added in the epilogue. It is not fetched by a load of its
+        // own (a compiler-issued load in front of the hand-counted ones made hipcc drain the whole queue before the
+        // first MFMA of every layer): it rides the weight stream as the fragment behind each tile's last k-step.
+#pragma unroll
+        for (uint32_t a = 0; a < TN; ++a)
+          acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[a], xb[m % 3], decltype(first)::value ? zero4 : acc[a][m], 0, 0, 0);
+      }
+    };
+    using TwoSets = std::integral_constant<int, 2 * TN>;
+    loadW(wB, 1);
+    loadW(wC, 2); landed(wA, TwoSets{}); step(wA, 0, std::true_type{});
+    loadW(wA, 3); landed(wB, TwoSets{}); if (1 < kSteps) step(wB, 1, std::false_type{});
+    loadW(wB, 4); landed(wC, TwoSets{}); if (2 < kSteps) step(wC, 2, std::false_type{});
+    for (uint32_t ks = 3; ks < kSteps; ks += 3) {
+      loadW(wC, ks + 2); landed(wA, TwoSets{}); step(wA, ks, std::false_type{});
+      loadW(wA, ks + 3); landed(wB, TwoSets{}); if (ks + 1 < kSteps) step(wB, ks + 1, std::false_type{});
+      loadW(wB, ks + 4); landed(wC, TwoSets{}); if (ks + 2 < kSteps) step(wC, ks + 2, std::false_type{});
+    }
+    // drain: the two sets still in flight own their registers until they land
+    asm volatile("s_waitcnt vmcnt(0)");
+#pragma unroll
+    for (uint32_t a = 0; a < TN; ++a) { asm volatile("; landed %0" : "+v"(wA[a])); asm volatile("; landed %0" : "+v"(wB[a])); asm volatile("; landed %0" : "+v"(wC[a])); }
+    // the last load into wA was past the end for every kSteps >= 1: it holds the tiles' bias fragments
+#pragma unroll
+    for (uint32_t a = 0; a < TN; ++a) bv[a] = __builtin_bit_cast(f4v, wA[a]);
   }
-  __syncthreads();
+  epilogue(P.layers[l1 - 1]);
 }
 
 // The MLP. rows: `numRows` (or *countPtr when countPtr != nullptr) entries; entry r reads
@@ -351,6 +388,7 @@ __global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : 1) nif_ml
                                                       uint32_t numRows, float* __restrict__ bgrOut, mi_trace_result* rays, bool scatter) {
   constexpr uint32_t kNifRows = 16u * MT * RG;                    // rays per workgroup pass
   extern __shared__ __attribute__((aligned(16))) _Float16 X[];   // [kNifRows][P.stride]
+  __shared__ float uvS[2 * kNifRows];                            // the pass's environment coordinates, fetched once
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t ng = wave & 3u, rowBase = 16u * MT * (wave >> 2);   // output-feature group, row group
   const uint32_t total = countPtr ? *countPtr : numRows;
@@ -366,11 +404,18 @@ __global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : 1) nif_ml
       const uint32_t r = e % kNifRows, c = e / kNifRows;
       X[r * stride + P.featBase + F + c] = (_Float16)0.f;
     }
+    // every row's (u, v) is needed by 2E feature columns: fetch it once (index, then coordinate: two dependent global
+    // loads per row instead of per feature) and hand it round through LDS
+    for (uint32_t r = tid; r < kNifRows; r += blockDim.x) {
+      const uint32_t row = row0 + r;
+      float cu = 0.f, cv = 0.f;
+      if (row < total) { const uint32_t src = idx ? idx[row] : row; cu = u[src]; cv = v[src]; }
+      uvS[r] = cu; uvS[kNifRows + r] = cv;
+    }
+    __syncthreads();
     for (uint32_t e = tid; e < kNifRows * E * 2; e += blockDim.x) {
       const uint32_t r = e % kNifRows, q = e / kNifRows, isV = q >= E ? 1u : 0u, j = q - isV * E;
-      const uint32_t row = row0 + r;
-      float coord = 0.f;
-      if (row < total) { const uint32_t src = idx ? idx[row] : row; coord = isV ? v[src] : u[src]; }
+      const float coord = uvS[isV * kNifRows + r];
       const float nrm = (coord - 1.f) * 2.f;                                  // NifModel.cpp:203-205
       const float phase = (float)(_Float16)(nrm * (float)(1u << j));           // cast to HALF before sin/cos (:212)
       float fs, fc;
@@ -382,18 +427,23 @@ __global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : 1) nif_ml
     }
     __syncthreads();
 
-    for (uint32_t l = 0; l < P.numLayers; ++l) {
-      const NifLayerDesc L = P.layers[l];
-      const bool last = (l + 1 == P.numLayers);
-      const uint32_t tilesLayer = L.nTiles >> 2;            // tiles per wave in this layer (wave-uniform)
-#define MI_NIF_LAYER(TN) nif_dense_layer<TN, MT>(P, L, last, X, stride, rowBase, ng, lane, weights, bias, row0, total, idx, bgrOut, rays, scatter)
-      if (tilesLayer == TILES) MI_NIF_LAYER(TILES);
-      else if (TILES > 1 && tilesLayer == 1) MI_NIF_LAYER(1);
-      else if (TILES > 2 && tilesLayer == 2) MI_NIF_LAYER(2);
-      else if (TILES > 3 && tilesLayer == 3) MI_NIF_LAYER(3);
-      else if (TILES > 4 && tilesLayer == 4) MI_NIF_LAYER(4);
-      else if (TILES > 5 && tilesLayer == 5) MI_NIF_LAYER(5);
-#undef MI_NIF_LAYER
+    for (uint32_t l = 0; l < P.numLayers;) {
+      // consecutive layers that give a wave the same number of output-feature tiles run as one pipelined loop; the
+      // network's final layer (decode + global stores in its epilogue) is always a run of its own
+      const uint32_t tilesLayer = P.layers[l].nTiles >> 2;            // (wave-uniform)
+      const bool finalLayer = l + 1 == P.numLayers;
+      uint32_t l1 = l + 1;
+      while (!finalLayer && l1 + 1 < P.numLayers && (P.layers[l1].nTiles >> 2) == tilesLayer) ++l1;
+#define MI_NIF_RUN(TN) do { if (finalLayer) nif_dense_layers<TN, MT, true>(P, l, l1, X, stride, rowBase, ng, lane, weights, bias, row0, total, idx, bgrOut, rays, scatter); \
+                            else nif_dense_layers<TN, MT, false>(P, l, l1, X, stride, rowBase, ng, lane, weights, bias, row0, total, idx, bgrOut, rays, scatter); } while (0)
+      if (tilesLayer == TILES) MI_NIF_RUN(TILES);
+      if constexpr (TILES > 1) { if (tilesLayer == 1) MI_NIF_RUN(1); }
+      if constexpr (TILES > 2) { if (tilesLayer == 2) MI_NIF_RUN(2); }
+      if constexpr (TILES > 3) { if (tilesLayer == 3) MI_NIF_RUN(3); }
+      if constexpr (TILES > 4) { if (tilesLayer == 4) MI_NIF_RUN(4); }
+      if constexpr (TILES > 5) { if (tilesLayer == 5) MI_NIF_RUN(5); }
+#undef MI_NIF_RUN
+      l = l1;
     }
   }
 }
