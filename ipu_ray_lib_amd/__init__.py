@@ -159,7 +159,8 @@ def device_lib() -> C.CDLL:
             import torch  # noqa: F401
         except ImportError:
             pass
-        lib = _load(PKG_DIR / "libmi_raylib.so")
+        # (MI_RAYLIB_LIB: another build of the same library, for A/B timing of two builds on one box)
+        lib = _load(Path(os.environ["MI_RAYLIB_LIB"]) if os.environ.get("MI_RAYLIB_LIB") else PKG_DIR / "libmi_raylib.so")
         lib.mi_last_error.restype = C.c_char_p
         lib.mi_version.restype = C.c_char_p
         lib.mi_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]

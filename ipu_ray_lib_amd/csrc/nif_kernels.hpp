@@ -395,15 +395,18 @@ __global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : 1) nif_ml
   const uint32_t stride = P.stride;
   const uint32_t E = P.embedDim, F = 4 * E;
 
-  for (uint32_t row0 = blockIdx.x * kNifRows; row0 < total; row0 += gridDim.x * kNifRows) {
-    __syncthreads();   // previous pass finished with X
-    // zero the K-padding columns behind the features, then write the Fourier features. Items are numbered
-    // column-major (e = column * kNifRows + row) so the row/column split divides by a compile-time constant.
+  // The K-padding columns behind the features are zero and nothing ever writes them again: once per workgroup, not
+  // once per pass. Items are numbered column-major (e = column * kNifRows + row) so the row/column split divides by a
+  // compile-time constant.
+  {
     const uint32_t padCols = stride - P.featBase - F;
     for (uint32_t e = tid; e < kNifRows * padCols; e += blockDim.x) {
       const uint32_t r = e % kNifRows, c = e / kNifRows;
       X[r * stride + P.featBase + F + c] = (_Float16)0.f;
     }
+  }
+  for (uint32_t row0 = blockIdx.x * kNifRows; row0 < total; row0 += gridDim.x * kNifRows) {
+    __syncthreads();   // previous pass finished with X
     // every row's (u, v) is needed by 2E feature columns: fetch it once (index, then coordinate: two dependent global
     // loads per row instead of per feature) and hand it round through LDS
     for (uint32_t r = tid; r < kNifRows; r += blockDim.x) {
