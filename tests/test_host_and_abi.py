@@ -265,9 +265,15 @@ def test_device_library_fails_loudly_without_gpu_or_on_bad_input():
     if not torch.cuda.is_available():
         with pytest.raises(irl.RaylibError):
             irl.IpuScene(s.desc)                                   # no silent CPU fallback
+        with pytest.raises(irl.RaylibError):
+            irl.IpuGroup(s.desc, [0, 0])                           # nor for the multi-replica renderer
     h = C.c_void_p()
     assert irl.device_lib().mi_scene_create(None, C.byref(h)) == 1  # MI_ERR_INVALID_ARG
     assert b"null" in irl.device_lib().mi_last_error()
+    dev = np.zeros(1, np.int32)
+    assert irl.device_lib().mi_group_create(C.byref(s.desc), dev.ctypes.data, 0, 0, C.byref(h)) == 1      # no replicas
+    assert irl.device_lib().mi_group_create(C.byref(s.desc), dev.ctypes.data, 65, 0, C.byref(h)) == 1     # too many
+    assert irl.device_lib().mi_scene_set_option(None, b"kernel", b"1") == 1
 
 
 def test_product_does_not_reach_into_the_oracle():
