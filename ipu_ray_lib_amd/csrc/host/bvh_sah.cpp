@@ -242,6 +242,22 @@ void buildCompactBvh(const std::vector<BuildPrim>& prims, std::vector<mi_bvh_nod
       if (std::getenv("MI_BVH_VERBOSE")) std::fprintf(stderr, "[bvh] reinsertion: %d moves, interior area %.6g -> %.6g\n", moved, a0, r.interiorArea());
     }
   }
+  {
+    // Child order. The walk always takes the first child first (CompactBvh.hpp:132-133), so the first child should
+    // be the one more likely to hold the closest hit: what is found there prunes the other. The reference moves every
+    // scene so that the camera sits at the origin (src/scene_utils.cpp:58-120), a third of all casts are primary
+    // rays from there, and the rest start on surfaces those rays reach; "the child whose box centre is nearer to the
+    // origin first" measured best of six static rules (oracle counters, 160x160 x 8 spp): box scene 18.85 -> 18.79
+    // box tests and 2.35 -> 2.26 primitive tests per cast, test_scene.dae 27.9 -> 26.1 and 3.22 -> 2.98, monkey bust
+    // 2.64 -> 2.37 and 0.150 -> 0.112 (larger-area-first: 18.83 / 2.33; smaller-area-first, farther-first and
+    // fewer-primitives-first are worse than no rule). MI_BVH_ORDER=0 keeps the builder's order.
+    const char* e = std::getenv("MI_BVH_ORDER");
+    if (!(e && e[0] == '0')) {
+      auto dist2 = [](const Bounds& x) { const f3 c = (x.lo + x.hi) * .5f; return (double)c.x * c.x + (double)c.y * c.y + (double)c.z * c.z; };
+      for (auto& n : b.tree)
+        if (n.prim < 0 && dist2(b.tree[n.child[1]].box) < dist2(b.tree[n.child[0]].box)) std::swap(n.child[0], n.child[1]);
+    }
+  }
   nodes.reserve(2 * prims.size() - 1);
   flatten(b, root, nodes, 1, maxDepth);
 }

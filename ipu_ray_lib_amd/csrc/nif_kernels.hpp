@@ -502,7 +502,10 @@ __global__ void __launch_bounds__(256) nif_accumulate_kernel(mi_trace_result* ra
     for (uint32_t s = s0; s < s1; ++s) {
       const size_t q = (size_t)s * n + i;
       rgb.x += color[3 * q]; rgb.y += color[3 * q + 1]; rgb.z += color[3 * q + 2];
-      if (u[q] >= 0.f) {
+      // u == -1 is the "did not escape" mark of the trace kernel; an escaped ray's u is theta / pi in [0, 1] - or NaN when
+      // the direction's y rounded to just outside [-1, 1] (acosf), and such a ray still takes its environment term, as
+      // in the reference's per-sample form (found by tests/fuzz_parity.py nif, seed 20261005 case 8486)
+      if (u[q] != -1.f) {
         rgb.x += tp[3 * q] * bgr[3 * q + 2];
         rgb.y += tp[3 * q + 1] * bgr[3 * q + 1];
         rgb.z += tp[3 * q + 2] * bgr[3 * q];

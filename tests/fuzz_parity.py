@@ -107,7 +107,9 @@ class Mismatch(AssertionError):
     pass
 
 
-def nif_campaign(budget, seed, max_cases=None):
+def nif_campaign(budget, seed, max_cases=None, replay_case=None):
+    """replay_case: draw the random parameters of every case but render only that one - five times with each batched
+    kernel against the literal loop, reporting per kernel - to look at a mismatch a long campaign found."""
     rng = np.random.default_rng(seed)
     builtins = {n: irl.HostScene.builtin(n) for n in ("box-simple", "box", "spheres", "monkey")}
     t_end = time.time() + budget
@@ -142,7 +144,19 @@ def nif_campaign(budget, seed, max_cases=None):
             dev.close()
             return rays
 
-        literal, batched = render("0"), render(str(rng.choice(["1", "3"])))
+        pick = str(rng.choice(["1", "3"]))
+        if replay_case is not None:
+            if case < replay_case:
+                continue
+            print(desc, "campaign kernel", pick, flush=True)
+            literal = render("0")
+            print("literal loop repeatable:", differing(render("0"), literal).size == 0, flush=True)
+            for kern in ("1", "3"):
+                for rep in range(5):
+                    bad = differing(render(kern), literal)
+                    print(f"  kernel {kern} run {rep}: {bad.size} TraceResults differ" + (f", first {int(bad[0])}" if bad.size else ""), flush=True)
+            return case, 0
+        literal, batched = render("0"), render(pick)
         bad = differing(batched, literal)
         if bad.size:
             i = int(bad[0])
@@ -218,7 +232,7 @@ def campaign(budget=240.0, seed=1, scale=1, max_cases=None):
 def main():
     try:
         if len(sys.argv) > 4 and sys.argv[4] == "nif":
-            nif_campaign(float(sys.argv[1]), int(sys.argv[2]))
+            nif_campaign(float(sys.argv[1]), int(sys.argv[2]), replay_case=int(sys.argv[5]) if len(sys.argv) > 5 else None)
         else:
             campaign(float(sys.argv[1]) if len(sys.argv) > 1 else 240.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
                      int(sys.argv[3]) if len(sys.argv) > 3 else 1)

@@ -5,6 +5,7 @@ IEEE operations (+ - * / sqrt), so there is no tolerance to state — except for
 tolerance is written in its test.
 """
 import ctypes as C
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -906,3 +907,34 @@ def test_replica_group_on_every_visible_gpu(scenes):
     assert grp.last_transfer()["rccl_messages"] == n_dev - 1
     grp.close()
     d.set_image(96, 64); d.samples_per_pixel = 5
+
+
+def test_nif_escaped_ray_with_nan_environment_coordinate(scenes):
+    """A case the long fuzz campaign found (tests/fuzz_parity.py nif, seed 20261005, case 8486; parameters and the
+    weight generator's state in tests/golden/nif_nan_coordinate_case.json): one escaped ray's direction has |y|
+    rounding just past 1, so PreProcessEscapedRays' acosf (codelets/TraceCodelets.cpp:330) gives NaN for u. The ray has
+    escaped all the same and takes the environment term of whatever the MLP makes of that input - in the reference's
+    per-sample form, in the oracle, and in the batched form, which used to read "u >= 0" as "escaped" and skipped it."""
+    import json
+    import fuzz_parity
+    case = json.loads((Path(__file__).parent / "golden" / "nif_nan_coordinate_case.json").read_text())
+    rng = np.random.default_rng(0)
+    rng.bit_generator.state = case["weights_rng_state"]
+    ks, bs, relu = fuzz_parity.nif_weights(rng, case["hidden"], 12, case["layers"])
+    s = scenes[case["scene"]]; d = s.desc
+    d.set_image(case["width"], case["height"]); d.samples_per_pixel = case["spp"]; d.path_trace = 1
+    d.rng_seed = case["rng_seed"]; d.anti_alias_scale = case["anti_alias_scale"]
+    d.max_path_length = case["max_path_length"]; d.roulette_start_depth = case["roulette_start_depth"]
+    mean = np.array([-2.35, -2.26, -1.96], np.float32)
+
+    def render(kernel):
+        dev = irl.IpuScene(d).set_option("kernel", kernel).set_option("nif_spl", case["nif_spl"])
+        dev.setNif(ks, bs, relu, 12, 3.43, mean, True)
+        dev.setHdriRotation(case["hdri_rotation"])
+        rays = s.init_ray_stream(); dev.run(rays, irl.MODE_PATH_TRACE); dev.close()
+        return rays
+
+    literal = render("0")
+    for kernel in ("1", "3"):
+        assert_streams_identical(render(kernel), literal, f"NaN environment coordinate, kernel {kernel}")
+    d.set_image(96, 64); d.samples_per_pixel = 5; d.rng_seed = 1442; d.anti_alias_scale = 0.25; d.max_path_length = 10; d.roulette_start_depth = 3
