@@ -34,7 +34,29 @@
 #include "ray_math.h"
 #include "../../include/mi_raylib.h"
 
+#ifndef MI_NIF_STAMPS
+#define MI_NIF_STAMPS 0
+#endif
+
 namespace mi {
+
+#if MI_NIF_STAMPS
+// diagnostic build only (tools/nif_stamps.py): where one wave's cycles go. [0] k-loops, [1] wait at the barrier after a
+// k-loop, [2] epilogue body, [3] wait at the barrier after it, [4] staging, [5] kernel total, [6] waves counted
+__device__ unsigned long long nif_stamps[8];
+__device__ __forceinline__ unsigned long long nif_now() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define MI_STAMP(var) const unsigned long long var = nif_now()
+#define MI_STAMP_ADD(slot, a, b) stampSum[slot] += (b) - (a)
+#else
+#define MI_STAMP(var)
+#define MI_STAMP_ADD(slot, a, b)
+#endif
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -184,6 +206,15 @@ __device__ __forceinline__ void sincos_half_phase(float p, float& sn, float& cs)
   cs = __builtin_amdgcn_cosf(rev);
 }
 
+// Column swizzle of the activation image X[ray][column]: rows whose index has bit 2 set keep every pair of 16-byte
+// chunks swapped (column ^ 8 halves). Row starts are 8 banks apart (stride = 32k + 16 halves), which is what
+// ds_read_b128's lane groups want (MI355X_MICROARCH.md, LDS table: 16 disjoint 4-bank slots per group) but puts rows
+// r, r+4, r+8, r+12 of a ds_write_b64 group (16 consecutive lanes = 16 rows, one column) on the same banks mod 32:
+// the epilogue's stores were 4-way conflicts (SQ_LDS_BANK_CONFLICT = 12 extra cycles per store). With the swap they
+// are 2-way (8 array cycles against the 6 the instruction needs anyway), the reads stay conflict-free, and the
+// swizzle is a per-lane constant in every address.
+__device__ __forceinline__ uint32_t nif_swizzle(uint32_t row) { return ((row >> 2) & 1u) << 3; }
+
 // PreProcessEscapedRays + compaction. u/v are written for EVERY ray (0 for rays that did not escape,
 // as the reference does); `index[0..*count)` receives the escaped rays' indices, one atomic per wave.
 __global__ void __launch_bounds__(256) escaped_uv_kernel(const mi_trace_result* rays, uint32_t n, float azimuthRotation,
@@ -232,7 +263,11 @@ template <uint32_t TN, uint32_t MT, bool LAST>
 __device__ __forceinline__ void nif_dense_layers(const NifParams& P, uint32_t l0, uint32_t l1, _Float16* X, uint32_t stride,
                                                  uint32_t rowBase, uint32_t ng, uint32_t lane, const h8* __restrict__ weights,
                                                  const float* __restrict__ bias, uint32_t row0, uint32_t total,
-                                                 const uint32_t* __restrict__ idx, float* __restrict__ bgrOut, mi_trace_result* rays, bool scatter) {
+                                                 const uint32_t* __restrict__ idx, float* __restrict__ bgrOut, mi_trace_result* rays, bool scatter
+#if MI_NIF_STAMPS
+                                                 , unsigned long long (&stampSum)[8]
+#endif
+                                                 ) {
   constexpr bool last = LAST;
   f4v acc[TN][MT];
   f4v bv[TN];
@@ -245,14 +280,17 @@ __device__ __forceinline__ void nif_dense_layers(const NifParams& P, uint32_t l0
 
   // bias / ReLU / binary16 store of layer EL (or decode + environment add), between the two barriers that separate
   // its k-loop's reads of X from these writes and these writes from the next k-loop's reads
+  const uint32_t laneCol = (4 * (lane >> 4)) ^ nif_swizzle(lane);   // row = lane mod 16 (+ multiples of 16): the swizzle is a lane constant
   auto epilogue = [&](const NifLayerDesc& EL) {
+    MI_STAMP(tE0);
     __syncthreads();   // every wave has read its inputs: X[.., 0..N) may be overwritten
+    MI_STAMP(tE1);
 #pragma unroll
     for (uint32_t a = 0; a < TN; ++a) {
       const uint32_t nt = ng + 4 * a;
       if (16 * nt < EL.n) {
         // D fragment: rows (= output features) 16nt + 4(lane>>4) + reg, column (= ray) 16m + (lane&15)
-        const uint32_t f0 = 16 * nt + 4 * (lane >> 4);
+        const uint32_t f0 = 16 * nt + laneCol;
 #pragma unroll
         for (uint32_t m = 0; m < MT; ++m) {
           f4v y = acc[a][m] + bv[a];
@@ -288,7 +326,10 @@ __device__ __forceinline__ void nif_dense_layers(const NifParams& P, uint32_t l0
         }
       }
     }
+    MI_STAMP(tE2);
     __syncthreads();
+    MI_STAMP(tE3);
+    MI_STAMP_ADD(1, tE0, tE1); MI_STAMP_ADD(2, tE1, tE2); MI_STAMP_ADD(3, tE2, tE3);
   };
 
   for (uint32_t l = l0; l < l1; ++l) {
@@ -304,18 +345,23 @@ __device__ __forceinline__ void nif_dense_layers(const NifParams& P, uint32_t l0
     // wait stricter); tests/test_asm_pipeline_audit.py checks the generated code for stores / atomics / scratch in
     // flight together with these loads and for any touch of a destination before it has landed.
     h8 wA[TN], wB[TN], wC[TN];
+    // One scalar base per tile, fixed for the layer (all-scalar arithmetic on kernel arguments + ngU: SALU results, which
+    // a VMEM instruction may read without wait states - a v_readfirstlane result would need 5: §5.7 item 2), and ONE
+    // vector offset per k-step shared by the TN loads: lane*16 + 1 KiB * step. The address arithmetic used to be five
+    // scalar instructions per load; a lone wave issues about one instruction per four cycles beside its MFMAs
+    // (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost'), and those 25 per k-step were paid in full.
+    uint64_t wTile[TN];
+#pragma unroll
+    for (uint32_t a = 0; a < TN; ++a) {
+      const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((ngU + 4 * a) * (kSteps + 1)) << 10));
+      wTile[a] = (uint64_t)(uintptr_t)(weights + L.wOffset) + off;
+    }
     auto loadW = [&](h8 (&w)[TN], uint32_t ks) {
       ks = ks < kSteps ? ks : kSteps;                        // past the end: the tile's bias fragment (keeps the count uniform)
+      const uint32_t voff = laneOff + (ks << 10);
 #pragma unroll
-      for (uint32_t a = 0; a < TN; ++a) {
-        // all-scalar arithmetic (kernel arguments + ngU): the base is produced by SALU instructions, which a VMEM
-        // instruction may read without wait states (a v_readfirstlane result would need 5: §5.7 item 2)
-        // (32-bit offset arithmetic: there is no 64-bit scalar multiply; the offset is pinned scalar with
-        // readfirstlane; the 64-bit add that consumes it is SALU)
-        const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)((((ngU + 4 * a) * (kSteps + 1)) + ks) << 10));
-        const uint64_t sbase = (uint64_t)(uintptr_t)(weights + L.wOffset) + off;
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(w[a]) : "v"(laneOff), "s"(sbase));
-      }
+      for (uint32_t a = 0; a < TN; ++a)
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(w[a]) : "v"(voff), "s"(wTile[a]));
     };
     auto landed = [&](h8 (&w)[TN], auto outstanding) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(outstanding)::value));
@@ -326,37 +372,40 @@ __device__ __forceinline__ void nif_dense_layers(const NifParams& P, uint32_t l0
     loadW(wA, 0);
     if (l > l0) epilogue(P.layers[l - 1]);
 
-    // Activation fragments come from LDS through inline-asm reads as well, two in flight: hipcc otherwise emits
-    // "ds_read; s_waitcnt lgkmcnt(0); TN mfma" per ray tile, exposing the LDS latency MT times per k-step with only two
-    // waves per SIMD to cover it. Same hand-counted scheme: reads return in order, lgkmcnt(1) = all but the newest.
-    const uint32_t xAddr0 = (uint32_t)(uintptr_t)X + ((rowBase + (lane & 15)) * stride + L.inBase + 8 * (lane >> 4)) * 2u;
+    // Activation fragments come from LDS through inline-asm reads as well: hipcc otherwise emits "ds_read; s_waitcnt
+    // lgkmcnt(0); TN mfma" per ray tile, exposing the LDS latency MT times per k-step. Same hand-counted scheme: reads
+    // return in order, so lgkmcnt(2) = all but the newest two. The three-slot ring runs two ray tiles ahead of the MFMAs
+    // ACROSS k-steps: the last two tiles of a step already ask for the first two fragments of the next one (stamps
+    // showed a wave that restarts the ring every k-step, waiting out one LDS round trip in front of 30 MFMAs, keeping
+    // the matrix pipe only 56 % busy when it has it to itself). Tile m of every step uses slot m % kRing, and kRing
+    // divides MT (3 slots for 6 tiles, 4 for 4), so the slots - the registers - of a tile are the same in every step.
+    const uint32_t xAddr0 = (uint32_t)(uintptr_t)X + ((rowBase + (lane & 15)) * stride + L.inBase + ((8 * (lane >> 4)) ^ nif_swizzle(lane))) * 2u;
     const uint32_t mStep = 16u * stride * 2u;
+    constexpr uint32_t kRing = (MT % 3u == 0u) ? 3u : 4u;
+    static_assert(MT % kRing == 0 && MT >= 2, "the activation ring runs two tiles ahead and must divide the tiles of a step");
+    h8 xb[kRing];
     auto readX = [&](h8& x, uint32_t addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(x) : "v"(addr)); };
     auto step = [&](const h8 (&w)[TN], uint32_t ks, auto first) {
       // B fragment: X^T[k][ray] = X[ray = rowBase + 16m + (lane&15)][k = 32ks + 8(lane>>4) + j]
       const uint32_t a0 = xAddr0 + 64u * ks;
-      h8 xb[3];                                   // three-deep ring: reads run two ray tiles ahead of the MFMAs
-      readX(xb[0], a0);
-      if (MT > 1) readX(xb[1], a0 + mStep);
+      const uint32_t aNext = ks + 1 < kSteps ? a0 + 64u : a0;             // behind the last step: a harmless re-read, retired by the drain
 #pragma unroll
       for (uint32_t m = 0; m < MT; ++m) {
-        if (m + 2 < MT) {
-          readX(xb[(m + 2) % 3], a0 + (m + 2) * mStep);
-          asm volatile("s_waitcnt lgkmcnt(2)\n\t; landed %0" : "+v"(xb[m % 3]));
-        } else if (m + 1 < MT) {
-          asm volatile("s_waitcnt lgkmcnt(1)\n\t; landed %0" : "+v"(xb[m % 3]));
-        } else {
-          asm volatile("s_waitcnt lgkmcnt(0)\n\t; landed %0" : "+v"(xb[m % 3]));
-        }
+        if (m + 2 < MT) readX(xb[(m + 2) % kRing], a0 + (m + 2) * mStep);
+        else readX(xb[(m + 2) % kRing], aNext + (m + 2 - MT) * mStep);
+        asm volatile("s_waitcnt lgkmcnt(2)\n\t; landed %0" : "+v"(xb[m % kRing]));
         // the first k-step's MFMAs take C = 0; the bias is added in the epilogue. It is not fetched by a load of its
         // own (a compiler-issued load in front of the hand-counted ones made hipcc drain the whole queue before the
         // first MFMA of every layer): it rides the weight stream as the fragment behind each tile's last k-step.
 #pragma unroll
         for (uint32_t a = 0; a < TN; ++a)
-          acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[a], xb[m % 3], decltype(first)::value ? zero4 : acc[a][m], 0, 0, 0);
+          acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[a], xb[m % kRing], decltype(first)::value ? zero4 : acc[a][m], 0, 0, 0);
       }
     };
     using TwoSets = std::integral_constant<int, 2 * TN>;
+    MI_STAMP(tK0);
+    readX(xb[0], xAddr0);
+    readX(xb[1], xAddr0 + mStep);
     loadW(wB, 1);
     loadW(wC, 2); landed(wA, TwoSets{}); step(wA, 0, std::true_type{});
     loadW(wA, 3); landed(wB, TwoSets{}); if (1 < kSteps) step(wB, 1, std::false_type{});
@@ -366,13 +415,17 @@ __device__ __forceinline__ void nif_dense_layers(const NifParams& P, uint32_t l0
       loadW(wA, ks + 3); landed(wB, TwoSets{}); if (ks + 1 < kSteps) step(wB, ks + 1, std::false_type{});
       loadW(wB, ks + 4); landed(wC, TwoSets{}); if (ks + 2 < kSteps) step(wC, ks + 2, std::false_type{});
     }
-    // drain: the two sets still in flight own their registers until they land
-    asm volatile("s_waitcnt vmcnt(0)");
+    // drain: the two weight sets and the two activation fragments still in flight own their registers until they land
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
 #pragma unroll
     for (uint32_t a = 0; a < TN; ++a) { asm volatile("; landed %0" : "+v"(wA[a])); asm volatile("; landed %0" : "+v"(wB[a])); asm volatile("; landed %0" : "+v"(wC[a])); }
+#pragma unroll
+    for (uint32_t q = 0; q < kRing; ++q) asm volatile("; landed %0" : "+v"(xb[q]));
     // the last load into wA was past the end for every kSteps >= 1: it holds the tiles' bias fragments
 #pragma unroll
     for (uint32_t a = 0; a < TN; ++a) bv[a] = __builtin_bit_cast(f4v, wA[a]);
+    MI_STAMP(tK1);
+    MI_STAMP_ADD(0, tK0, tK1);
   }
   epilogue(P.layers[l1 - 1]);
 }
@@ -394,6 +447,10 @@ __global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : 1) nif_ml
   const uint32_t total = countPtr ? *countPtr : numRows;
   const uint32_t stride = P.stride;
   const uint32_t E = P.embedDim, F = 4 * E;
+#if MI_NIF_STAMPS
+  unsigned long long stampSum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long tBegin = nif_now();
+#endif
 
   // The K-padding columns behind the features are zero and nothing ever writes them again: once per workgroup, not
   // once per pass. Items are numbered column-major (e = column * kNifRows + row) so the row/column split divides by a
@@ -402,22 +459,38 @@ __global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : 1) nif_ml
     const uint32_t padCols = stride - P.featBase - F;
     for (uint32_t e = tid; e < kNifRows * padCols; e += blockDim.x) {
       const uint32_t r = e % kNifRows, c = e / kNifRows;
-      X[r * stride + P.featBase + F + c] = (_Float16)0.f;
+      X[r * stride + ((P.featBase + F + c) ^ nif_swizzle(r))] = (_Float16)0.f;
     }
   }
+  // Two row groups (RG == 2) run HALF A PHASE APART: the second group passes one extra barrier here and the first one
+  // at the very end, so every workgroup barrier still sees all eight waves but group 1's n-th phase runs beside group
+  // 0's (n+1)-th. The phases of a group alternate between a k-loop (matrix cores) and an epilogue / staging phase
+  // (VALU + LDS), and each SIMD holds one wave of either group: with the offset a SIMD's matrix pipe always has
+  // exactly one wave feeding it while its partner converts and stores, instead of both waves competing for the pipe
+  // and then both leaving it idle (MI355X_MICROARCH.md, "Two waves per SIMD", item 5: a rendezvous pays when the
+  // paired intervals are complementary). The groups share no rows, so every phase touches only its own group's part
+  // of X and uvS and the barriers order exactly what they ordered before.
+  constexpr uint32_t kGroupRows = 16u * MT, kGroupThreads = 256u;
+  const uint32_t gtid = tid & (kGroupThreads - 1u);
+  if (RG == 2) {
+    __syncthreads();
+    if (wave >= 4) __builtin_amdgcn_s_barrier();
+  }
   for (uint32_t row0 = blockIdx.x * kNifRows; row0 < total; row0 += gridDim.x * kNifRows) {
+    MI_STAMP(tS0);
     __syncthreads();   // previous pass finished with X
     // every row's (u, v) is needed by 2E feature columns: fetch it once (index, then coordinate: two dependent global
     // loads per row instead of per feature) and hand it round through LDS
-    for (uint32_t r = tid; r < kNifRows; r += blockDim.x) {
-      const uint32_t row = row0 + r;
+    // (each row group stages its own rows with its own 256 threads)
+    for (uint32_t rr = gtid; rr < kGroupRows; rr += kGroupThreads) {
+      const uint32_t r = rowBase + rr, row = row0 + r;
       float cu = 0.f, cv = 0.f;
       if (row < total) { const uint32_t src = idx ? idx[row] : row; cu = u[src]; cv = v[src]; }
       uvS[r] = cu; uvS[kNifRows + r] = cv;
     }
     __syncthreads();
-    for (uint32_t e = tid; e < kNifRows * E * 2; e += blockDim.x) {
-      const uint32_t r = e % kNifRows, q = e / kNifRows, isV = q >= E ? 1u : 0u, j = q - isV * E;
+    for (uint32_t e = gtid; e < kGroupRows * E * 2; e += kGroupThreads) {
+      const uint32_t r = rowBase + e % kGroupRows, q = e / kGroupRows, isV = q >= E ? 1u : 0u, j = q - isV * E;
       const float coord = uvS[isV * kNifRows + r];
       const float nrm = (coord - 1.f) * 2.f;                                  // NifModel.cpp:203-205
       const float phase = (float)(_Float16)(nrm * (float)(1u << j));           // cast to HALF before sin/cos (:212)
@@ -425,10 +498,12 @@ __global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : 1) nif_ml
       sincos_half_phase(phase, fs, fc);
       const _Float16 sn = (_Float16)fs, cs = (_Float16)fc;
       // feature order [sin u | sin v | cos u | cos v] (NifModel.cpp:216)
-      X[r * stride + P.featBase + q] = sn;
-      X[r * stride + P.featBase + 2 * E + q] = cs;
+      X[r * stride + ((P.featBase + q) ^ nif_swizzle(r))] = sn;
+      X[r * stride + ((P.featBase + 2 * E + q) ^ nif_swizzle(r))] = cs;
     }
     __syncthreads();
+    MI_STAMP(tS1);
+    MI_STAMP_ADD(4, tS0, tS1);
 
     for (uint32_t l = 0; l < P.numLayers;) {
       // consecutive layers that give a wave the same number of output-feature tiles run as one pipelined loop; the
@@ -437,8 +512,13 @@ __global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : 1) nif_ml
       const bool finalLayer = l + 1 == P.numLayers;
       uint32_t l1 = l + 1;
       while (!finalLayer && l1 + 1 < P.numLayers && (P.layers[l1].nTiles >> 2) == tilesLayer) ++l1;
-#define MI_NIF_RUN(TN) do { if (finalLayer) nif_dense_layers<TN, MT, true>(P, l, l1, X, stride, rowBase, ng, lane, weights, bias, row0, total, idx, bgrOut, rays, scatter); \
-                            else nif_dense_layers<TN, MT, false>(P, l, l1, X, stride, rowBase, ng, lane, weights, bias, row0, total, idx, bgrOut, rays, scatter); } while (0)
+#if MI_NIF_STAMPS
+#define MI_NIF_STAMP_ARG , stampSum
+#else
+#define MI_NIF_STAMP_ARG
+#endif
+#define MI_NIF_RUN(TN) do { if (finalLayer) nif_dense_layers<TN, MT, true>(P, l, l1, X, stride, rowBase, ng, lane, weights, bias, row0, total, idx, bgrOut, rays, scatter MI_NIF_STAMP_ARG); \
+                            else nif_dense_layers<TN, MT, false>(P, l, l1, X, stride, rowBase, ng, lane, weights, bias, row0, total, idx, bgrOut, rays, scatter MI_NIF_STAMP_ARG); } while (0)
       if (tilesLayer == TILES) MI_NIF_RUN(TILES);
       if constexpr (TILES > 1) { if (tilesLayer == 1) MI_NIF_RUN(1); }
       if constexpr (TILES > 2) { if (tilesLayer == 2) MI_NIF_RUN(2); }
@@ -449,6 +529,12 @@ __global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : 1) nif_ml
       l = l1;
     }
   }
+  if (RG == 2 && wave < 4) __builtin_amdgcn_s_barrier();
+#if MI_NIF_STAMPS
+  stampSum[5] = nif_now() - tBegin; stampSum[6] = 1;
+  if (lane == 0 && (wave & 3u) == 1u)
+    for (int q = 0; q < 7; ++q) atomicAdd(&nif_stamps[q], stampSum[q]);
+#endif
 }
 
 // bgrOut: result of row r at bgrOut[3r..] - or, with `scatter`, at bgrOut[3*idx[r]..] (the row's own slot)
@@ -464,7 +550,10 @@ inline void nif_launch_mlp(const NifDevice& nif, const float* u, const float* v,
   if (shape != 0) { rg = 2; mt = (shape == 1) ? 6 : 4; }
   if (!(mt == 4 && rg == 2) && ((size_t)16 * mt * rg * nif.p.stride * sizeof(_Float16) > kNifMaxLdsBytes || maxTiles > 5)) { mt = 4; rg = 2; }
   auto launch = [&](auto kern, uint32_t rowsPerPass, uint32_t threads) {
-    const size_t lds = (size_t)rowsPerPass * nif.p.stride * sizeof(_Float16);
+    size_t lds = (size_t)rowsPerPass * nif.p.stride * sizeof(_Float16);
+#if MI_NIF_STAMPS
+    if (getenv("MI_NIF_DIAG_ONE_WG")) lds = kNifMaxLdsBytes;   // diagnostic: one workgroup per CU, i.e. one wave per SIMD for the 4-wave shape
+#endif
     uint32_t blocks = (numRows + rowsPerPass - 1) / rowsPerPass;
     if (blocks > 256 * 8) blocks = 256 * 8;          // grid-stride beyond 8 passes per CU
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNifMaxLdsBytes);

@@ -731,3 +731,13 @@ int mi_nif_infer_device(mi_scene* scene, const float* d_u, const float* d_v, flo
 }  // extern "C"
 
 #include "group_render.hpp"
+
+#if MI_NIF_STAMPS
+// diagnostic build only: reads and clears the NIF kernel's stamp sums (nif_kernels.hpp)
+extern "C" int mi_debug_nif_stamps(unsigned long long* out8) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(mi::nif_stamps), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(mi::nif_stamps), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
+
