@@ -81,7 +81,7 @@ struct NifLayerDesc {
 };
 
 struct NifParams {
-  uint32_t numLayers, embedDim, featBase, stride;   // stride in halves
+  uint32_t numLayers, embedDim, featBase, stride;   // stride: halves per ray in the LDS image (features included, padded to 32)
   float maxValue, mean[3];
   int32_t logTonemap;
   NifLayerDesc layers[kNifMaxLayers];
@@ -121,9 +121,7 @@ struct NifDevice {
     NifParams P{};
     P.numLayers = numLayers; P.embedDim = embedDim; P.featBase = featBase;
     const uint32_t kPadMax = ((featBase + F + 31u) & ~31u);
-    P.stride = kPadMax + 16;
-                     // +16 halves: rows start 8 banks apart -> the ds_read_b128 lane groups
-                                                  // (rows l&15, k-chunk l>>4) hit 16 disjoint 4-bank slots (measured: +8 gave 2-way conflicts)
+    P.stride = kPadMax;   // halves per ray (a multiple of 32); the image is k-chunk major (nif_x_byte)
     P.maxValue = maxValue; P.mean[0] = mean[0]; P.mean[1] = mean[1]; P.mean[2] = mean[2]; P.logTonemap = logTonemap;
     std::vector<_Float16> packed;
     std::vector<float> bias;
@@ -148,16 +146,9 @@ struct NifDevice {
       L.kSteps = (K + 31) / 32; L.nTiles = (((N + 15) / 16) + 3u) & ~3u; L.n = N; L.relu = relu[l] ? 1u : 0u;   // tiles padded to a multiple of 4: every wave owns nTiles/4 of them
       L.wOffset = (uint32_t)(packed.size() / 8);
       for (uint32_t nt = 0; nt < L.nTiles; ++nt) {
-        for (uint32_t ks = 0; ks < L.kSteps; ++ks)
-          for (uint32_t lane = 0; lane < 64; ++lane)
-            for (uint32_t j = 0; j < 8; ++j) {
-              const uint32_t k = ks * 32 + 8 * (lane >> 4) + j, n = nt * 16 + (lane & 15);
-              const float w = (k < K && n < N) ? kernels[l][(size_t)k * N + n] : 0.f;
-              packed.push_back((_Float16)w);
-            }
-        // fragment kSteps of the tile is not weights: lane l's 16 bytes are the four binary32 bias values of the
-        // output features its accumulator holds (16nt + 4(l>>4) + 0..3; zeros for a layer without bias). The weight
-        // pipeline's loads past the last k-step fetch it, so the bias arrives with the stream, for free.
+        // fragment 0 of the tile is not weights: lane l's 16 bytes are the four binary32 bias values of the output
+        // features its accumulator holds (16nt + 4(l>>4) + 0..3; zeros for a layer without bias). It heads the
+        // tile's stream, lands with the first weight fragments and is the C operand of the first k-step's MFMAs.
         for (uint32_t lane = 0; lane < 64; ++lane)
           for (uint32_t q = 0; q < 4; ++q) {
             const uint32_t n = nt * 16 + 4 * (lane >> 4) + q;
@@ -166,6 +157,13 @@ struct NifDevice {
             memcpy(two, &b, 4);
             packed.push_back(two[0]); packed.push_back(two[1]);
           }
+        for (uint32_t ks = 0; ks < L.kSteps; ++ks)
+          for (uint32_t lane = 0; lane < 64; ++lane)
+            for (uint32_t j = 0; j < 8; ++j) {
+              const uint32_t k = ks * 32 + 8 * (lane >> 4) + j, n = nt * 16 + (lane & 15);
+              const float w = (k < K && n < N) ? kernels[l][(size_t)k * N + n] : 0.f;
+              packed.push_back((_Float16)w);
+            }
       }
       if (biases && biases[l]) { L.bOffset = (uint32_t)bias.size(); for (uint32_t n = 0; n < N; ++n) bias.push_back(biases[l][n]); for (uint32_t n = N; n < L.nTiles * 16; ++n) bias.push_back(0.f); }
       else L.bOffset = 0xFFFFFFFFu;
@@ -206,14 +204,25 @@ __device__ __forceinline__ void sincos_half_phase(float p, float& sn, float& cs)
   cs = __builtin_amdgcn_cosf(rev);
 }
 
-// Column swizzle of the activation image X[ray][column]: rows whose index has bit 2 set keep every pair of 16-byte
-// chunks swapped (column ^ 8 halves). Row starts are 8 banks apart (stride = 32k + 16 halves), which is what
-// ds_read_b128's lane groups want (MI355X_MICROARCH.md, LDS table: 16 disjoint 4-bank slots per group) but puts rows
-// r, r+4, r+8, r+12 of a ds_write_b64 group (16 consecutive lanes = 16 rows, one column) on the same banks mod 32:
-// the epilogue's stores were 4-way conflicts (SQ_LDS_BANK_CONFLICT = 12 extra cycles per store). With the swap they
-// are 2-way (8 array cycles against the 6 the instruction needs anyway), the reads stay conflict-free, and the
-// swizzle is a per-lane constant in every address.
-__device__ __forceinline__ uint32_t nif_swizzle(uint32_t row) { return ((row >> 2) & 1u) << 3; }
+// The activation image in LDS, k-chunk major: X[kc][ray][32 halves], kc = column / 32, and inside a ray's 64 bytes the four
+// 16-byte pieces are stored at piece ^ S[(ray >> 2) & 3], S = {0, 2, 3, 1}.
+//   * the B fragment of (k-step ks, ray tile m) for lane (ray r = lane & 15, piece g = lane >> 4) is at
+//       laneBase + ks * (ROWS * 64) + m * 1024
+//     so the whole k-loop addresses its ds_read_b128 with ONE VGPR and compile-time offsets (a wave issues about one
+//     instruction per four cycles beside its MFMAs; with a row-major image every read cost a v_add of its own);
+//   * ds_read_b128 serves a wave in four 16-lane groups, {0-3,12-15,20-27} ... (MI355X_MICROARCH.md, LDS table): with
+//     the swap every group's 16 lanes hit 16 different 4-bank slots (checked over all groups / tiles / k-steps by
+//     enumeration, tests/test_host_and_abi.py) - conflict-free without padding, so the image is 12 x 96 x 64 B = 72 KiB;
+//   * the epilogue's ds_write_b64 (16 consecutive lanes = 16 rays, one column) is 2-way: 8 LDS cycles against the 6
+//     the instruction needs anyway (row-major with 8-bank row offsets it was 4-way: SQ_LDS_BANK_CONFLICT = 12 extra
+//     cycles per store).
+template <uint32_t ROWS>
+__device__ __forceinline__ uint32_t nif_x_byte(uint32_t ray, uint32_t col) {
+  const uint32_t sw = (0x78u >> (2u * ((ray >> 2) & 3u))) & 3u;            // S = {0, 2, 3, 1}, two bits each: 0b01'11'10'00
+  return (col >> 5) * (ROWS * 64u) + ray * 64u + ((((col >> 3) & 3u) ^ sw) << 4) + (col & 7u) * 2u;
+}
+template <typename F, uint32_t... I>
+__device__ __forceinline__ void nif_unroll(F&& f, std::integer_sequence<uint32_t, I...>) { (f(std::integral_constant<uint32_t, I>{}), ...); }
 
 // PreProcessEscapedRays + compaction. u/v are written for EVERY ray (0 for rays that did not escape,
 // as the reference does); `index[0..*count)` receives the escaped rays' indices, one atomic per wave.
@@ -247,20 +256,19 @@ __global__ void __launch_bounds__(256) escaped_uv_kernel(const mi_trace_result* 
 }
 
 // A RUN of dense layers [l0, l1) for one wave: all of them give the wave TN output-feature tiles (nt = ng + 4a) x MT ray
-// tiles, fully unrolled, with their own accumulators. Per layer: the k-loop (the next k-steps' weight fragments in
-// flight while the current ones feed the matrix cores), then the epilogue (bias, ReLU, binary16 store - or, for the
-// network's final layer, decode + environment add).
+// tiles, fully unrolled, with their own accumulators. Per layer: the k-loop, then the epilogue (ReLU, binary16 store -
+// or, for the network's final layer, decode + environment add).
 //
-// The loop is ROTATED: an iteration asks for its layer's k-step-0 fragments, THEN runs the previous layer's epilogue
-// (with its two barriers), THEN its own k-loop; the last layer's epilogue follows the loop. So the L2 latency of a
-// layer's first fragments is spent under the previous layer's epilogue instead of in front of its first MFMA, and no
-// register with a load in flight is carried around the loop's back edge: what IS carried are the accumulators and the
-// bias, ordinary values. (An earlier form issued the fragments at the END of the previous iteration; hipcc gave them
+// The loop is ROTATED: an iteration asks for its layer's bias and k-step-0 fragments, THEN runs the previous layer's
+// epilogue (with its two barriers), THEN its own k-loop; the last layer's epilogue follows the loop. So the L2 latency
+// of a layer's first fragments is spent under the previous layer's epilogue instead of in front of its first MFMA, and
+// no register with a load in flight is carried around the loop's back edge: what IS carried are the accumulators,
+// ordinary values. (An earlier form issued the fragments at the END of the previous iteration; hipcc gave them
 // registers of their own and copied those into the k-loop's at the loop header - before they had landed.
-// tests/test_asm_pipeline_audit.py now follows the control flow and catches that.)
+// tests/test_asm_pipeline_audit.py follows the control flow and catches that.)
 // LAST: the run is the network's final layer alone (decode + global stores in its epilogue).
-template <uint32_t TN, uint32_t MT, bool LAST>
-__device__ __forceinline__ void nif_dense_layers(const NifParams& P, uint32_t l0, uint32_t l1, _Float16* X, uint32_t stride,
+template <uint32_t TN, uint32_t MT, uint32_t ROWS, bool LAST>
+__device__ __forceinline__ void nif_dense_layers(const NifParams& P, uint32_t l0, uint32_t l1, _Float16* X,
                                                  uint32_t rowBase, uint32_t ng, uint32_t lane, const h8* __restrict__ weights,
                                                  const float* __restrict__ bias, uint32_t row0, uint32_t total,
                                                  const uint32_t* __restrict__ idx, float* __restrict__ bgrOut, mi_trace_result* rays, bool scatter
@@ -270,62 +278,68 @@ __device__ __forceinline__ void nif_dense_layers(const NifParams& P, uint32_t l0
                                                  ) {
   constexpr bool last = LAST;
   f4v acc[TN][MT];
-  f4v bv[TN];
-  const f4v zero4 = {0.f, 0.f, 0.f, 0.f};
-  // Fragment (nt, ks) is 1 KiB at weights + wOffset + (nt*(kSteps+1) + ks)*64 (+ lane): a wave-uniform base, so the
-  // loads use the SGPR-base + VGPR-offset form and need ONE address VGPR (lane*16) for all of them. Fragment kSteps of
-  // a tile is its bias (NifDevice::load).
+  // Fragment f of tile nt is 1 KiB at weights + wOffset + (nt*(kSteps+1) + f)*64 (+ lane): fragment 0 is the tile's
+  // bias, fragment 1 + ks the weights of k-step ks (NifDevice::load). A wave-uniform base per tile, so the loads use
+  // the SGPR-base + VGPR-offset form with ONE address VGPR (lane*16 + 1 KiB * fragment) for the TN loads of a step.
   const uint32_t laneOff = lane * 16u;
   const uint32_t ngU = (uint32_t)__builtin_amdgcn_readfirstlane((int)ng);
 
-  // bias / ReLU / binary16 store of layer EL (or decode + environment add), between the two barriers that separate
-  // its k-loop's reads of X from these writes and these writes from the next k-loop's reads
-  const uint32_t laneCol = (4 * (lane >> 4)) ^ nif_swizzle(lane);   // row = lane mod 16 (+ multiples of 16): the swizzle is a lane constant
+  // ReLU / binary16 store of layer EL (or decode + environment add), between the two barriers that separate its
+  // k-loop's reads of X from these writes and these writes from the next k-loop's reads. The bias is already in the
+  // accumulators (C operand of the first k-step).
+  // store address of the lane's 4 features of tile nt = ng + 4a, ray tile m: nif_x_byte(rowBase + 16m + (lane&15),
+  // 16nt + 4(lane>>4)) = laneStore + a * (2 * ROWS * 64) + m * 1024 - the parity of nt is the wave's (ng & 1)
+  const uint32_t laneStore = nif_x_byte<ROWS>(rowBase + (lane & 15), 16 * ng + 4 * (lane >> 4));
   auto epilogue = [&](const NifLayerDesc& EL) {
     MI_STAMP(tE0);
     __syncthreads();   // every wave has read its inputs: X[.., 0..N) may be overwritten
     MI_STAMP(tE1);
+    // one copy of the store loop per activation, chosen by a wave-uniform branch (as a select per value the choice
+    // cost two v_cndmask per accumulator)
+    auto body = [&](auto reluC) {
+      constexpr bool relu = decltype(reluC)::value;
 #pragma unroll
-    for (uint32_t a = 0; a < TN; ++a) {
-      const uint32_t nt = ng + 4 * a;
-      if (16 * nt < EL.n) {
-        // D fragment: rows (= output features) 16nt + 4(lane>>4) + reg, column (= ray) 16m + (lane&15)
-        const uint32_t f0 = 16 * nt + laneCol;
+      for (uint32_t a = 0; a < TN; ++a) {
+        const uint32_t nt = ng + 4 * a;
+        if (16 * nt < EL.n) {
+          // D fragment: rows (= output features) 16nt + 4(lane>>4) + reg, column (= ray) 16m + (lane&15)
 #pragma unroll
-        for (uint32_t m = 0; m < MT; ++m) {
-          f4v y = acc[a][m] + bv[a];
-          const uint32_t r = rowBase + 16 * m + (lane & 15);
-          if (!last) {
-            // ReLU on the rounded halves (two packed max): rounding is monotone and keeps the sign, so
-            // max(round(y), 0) == round(max(y, 0))
-            h4 yh = {(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
-            if (EL.relu) yh = __builtin_elementwise_max(yh, (h4){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f});
-            *reinterpret_cast<h4*>(&X[r * stride + f0]) = yh;
-          } else if (nt == 0 && (lane >> 4) == 0 && row0 + r < total) {
-            // decode (NifModel.cpp:222-246): y*max + mean, exp for log-tonemapped models
-            if (EL.relu) {
+          for (uint32_t m = 0; m < MT; ++m) {
+            f4v y = acc[a][m];
+            const uint32_t r = rowBase + 16 * m + (lane & 15);
+            if (!last) {
+              // ReLU on the rounded halves (two packed max): rounding is monotone and keeps the sign, so
+              // max(round(y), 0) == round(max(y, 0))
+              h4 yh = {(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
+              if (relu) yh = __builtin_elementwise_max(yh, (h4){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f});
+              *reinterpret_cast<h4*>(reinterpret_cast<char*>(X) + laneStore + a * (2u * ROWS * 64u) + m * 1024u) = yh;
+            } else if (nt == 0 && (lane >> 4) == 0 && row0 + r < total) {
+              // decode (NifModel.cpp:222-246): y*max + mean, exp for log-tonemapped models
+              if (relu) {
 #pragma unroll
-              for (int q = 0; q < 4; ++q) y[q] = y[q] > 0.f ? y[q] : 0.f;
-            }
-            float o[3];
+                for (int q = 0; q < 4; ++q) y[q] = y[q] > 0.f ? y[q] : 0.f;
+              }
+              float o[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              o[c] = y[c] * P.maxValue + P.mean[c];
-              if (P.logTonemap) o[c] = expf(o[c]);
-            }
-            const uint32_t row = row0 + r;
-            if (bgrOut) { const size_t dst = scatter ? (size_t)idx[row] : (size_t)row; bgrOut[3 * dst] = o[0]; bgrOut[3 * dst + 1] = o[1]; bgrOut[3 * dst + 2] = o[2]; }
-            if (rays) {
-              mi_trace_result* res = rays + (idx ? idx[row] : row);
-              const mi_vec3 tp = res->h.throughput;
-              res->rgb.x += tp.x * o[2];          // BGR -> RGB (codelets/TraceCodelets.cpp:376)
-              res->rgb.y += tp.y * o[1];
-              res->rgb.z += tp.z * o[0];
+              for (int c = 0; c < 3; ++c) {
+                o[c] = y[c] * P.maxValue + P.mean[c];
+                if (P.logTonemap) o[c] = expf(o[c]);
+              }
+              const uint32_t row = row0 + r;
+              if (bgrOut) { const size_t dst = scatter ? (size_t)idx[row] : (size_t)row; bgrOut[3 * dst] = o[0]; bgrOut[3 * dst + 1] = o[1]; bgrOut[3 * dst + 2] = o[2]; }
+              if (rays) {
+                mi_trace_result* res = rays + (idx ? idx[row] : row);
+                const mi_vec3 tp = res->h.throughput;
+                res->rgb.x += tp.x * o[2];          // BGR -> RGB (codelets/TraceCodelets.cpp:376)
+                res->rgb.y += tp.y * o[1];
+                res->rgb.z += tp.z * o[0];
+              }
             }
           }
         }
       }
-    }
+    };
+    if (EL.relu) body(std::true_type{}); else body(std::false_type{});
     MI_STAMP(tE2);
     __syncthreads();
     MI_STAMP(tE3);
@@ -335,95 +349,127 @@ __device__ __forceinline__ void nif_dense_layers(const NifParams& P, uint32_t l0
   for (uint32_t l = l0; l < l1; ++l) {
     const NifLayerDesc L = P.layers[l];
     const uint32_t kSteps = L.kSteps;
-    // Weight stream: three named fragment sets (k-steps 3j, 3j+1, 3j+2), each loaded two k-steps before it is used.
-    // hipcc sinks ordinary loads down to their first use here (it minimises live ranges at this register
-    // pressure: the .s showed "load, s_waitcnt vmcnt(0), mfma" every k-step), so the loads are inline asm, invisible
-    // to its scheduler, and their completion is counted by hand (cdna_hip_programming.md §5.7 form ii): loads return
-    // in order, every step issues exactly TN of them, so "all but the newest 2*TN have landed" is the set about to be
-    // used. Every destination is named in the wait ("; landed vN" for the audit), which keeps the consumers below it.
-    // The counts assume that only LOADS join the queue meanwhile (they return in order, so a younger one only makes a
-    // wait stricter); tests/test_asm_pipeline_audit.py checks the generated code for stores / atomics / scratch in
-    // flight together with these loads and for any touch of a destination before it has landed.
+    // The k-loop is written instruction by instruction (every statement below is a volatile asm, which hipcc keeps in
+    // program order; it only allocates the registers and adds the little address arithmetic that is left). Why: a
+    // wave issues about one instruction per four cycles, a v_mfma_f32_16x16x32_f16 occupies the matrix pipe for 16 and
+    // the issue port for 8 of them (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost'), so loads, LDS reads and
+    // waits are free only while they sit BETWEEN MFMAs. Stamps (tools/nif_stamps.py) showed a lone wave's k-loop at
+    // 1.7x its MFMA time with the compiler's placement (loads and five scalar instructions of address arithmetic each
+    // bunched in front of a k-step, a v_add per LDS read, s_nop pads behind every "landed" marker).
+    //   weight stream : three fragment sets; the set of k-step ks+2 is asked for in front of step ks (TN loads behind
+    //                   two instructions of address arithmetic); "all but the newest 2*TN loads have landed" (loads
+    //                   return in order) is the set about to be used - and, in step 0, the bias.
+    //   activations   : a ring of LDS reads two ray tiles ahead, across k-steps (the last two tiles of a step ask for
+    //                   the first two fragments of the next); tile m of every step uses slot m % kRing, kRing divides MT.
+    // Every destination is named behind its wait ("; landed vN") for tests/test_asm_pipeline_audit.py, which checks
+    // that nothing touches a destination in flight and that no store / atomic / scratch access joins the counted queue.
     h8 wA[TN], wB[TN], wC[TN];
-    // One scalar base per tile, fixed for the layer (all-scalar arithmetic on kernel arguments + ngU: SALU results, which
-    // a VMEM instruction may read without wait states - a v_readfirstlane result would need 5: §5.7 item 2), and ONE
-    // vector offset per k-step shared by the TN loads: lane*16 + 1 KiB * step. The address arithmetic used to be five
-    // scalar instructions per load; a lone wave issues about one instruction per four cycles beside its MFMAs
-    // (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost'), and those 25 per k-step were paid in full.
+    f4v bv[TN];
     uint64_t wTile[TN];
 #pragma unroll
     for (uint32_t a = 0; a < TN; ++a) {
+      // all-scalar arithmetic on kernel arguments + ngU: SALU results, which a VMEM instruction may read without wait
+      // states (a v_readfirstlane result would need 5: cdna_hip_programming.md §5.7 item 2)
       const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((ngU + 4 * a) * (kSteps + 1)) << 10));
       wTile[a] = (uint64_t)(uintptr_t)(weights + L.wOffset) + off;
     }
+#if defined(MI_NIF_KO) && (MI_NIF_KO & 1)
+    auto loadOne = [&](h8& w, uint32_t voff, uint32_t a) { asm volatile("; no load %0, %1, %2" : "+v"(w) : "v"(voff), "s"(wTile[a])); };
+#else
+    auto loadOne = [&](h8& w, uint32_t voff, uint32_t a) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(w) : "v"(voff), "s"(wTile[a])); };
+#endif
+    auto fragOff = [&](uint32_t ks) { return laneOff + ((1u + (ks < kSteps ? ks : kSteps - 1u)) << 10); };   // past the end: the last fragment again (keeps the count uniform)
     auto loadW = [&](h8 (&w)[TN], uint32_t ks) {
-      ks = ks < kSteps ? ks : kSteps;                        // past the end: the tile's bias fragment (keeps the count uniform)
-      const uint32_t voff = laneOff + (ks << 10);
+      const uint32_t voff = fragOff(ks);
 #pragma unroll
-      for (uint32_t a = 0; a < TN; ++a)
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(w[a]) : "v"(voff), "s"(wTile[a]));
+      for (uint32_t a = 0; a < TN; ++a) loadOne(w[a], voff, a);
     };
-    auto landed = [&](h8 (&w)[TN], auto outstanding) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(outstanding)::value));
+    // bias and k-step 0 first: they are in flight while the previous layer's epilogue runs
 #pragma unroll
-      for (uint32_t a = 0; a < TN; ++a) asm volatile("; landed %0" : "+v"(w[a]));
-    };
-    // k-step 0 first: it is in flight while the previous layer's epilogue runs
+    for (uint32_t a = 0; a < TN; ++a) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(bv[a]) : "v"(laneOff), "s"(wTile[a]));
     loadW(wA, 0);
     if (l > l0) epilogue(P.layers[l - 1]);
 
-    // Activation fragments come from LDS through inline-asm reads as well: hipcc otherwise emits "ds_read; s_waitcnt
-    // lgkmcnt(0); TN mfma" per ray tile, exposing the LDS latency MT times per k-step. Same hand-counted scheme: reads
-    // return in order, so lgkmcnt(2) = all but the newest two. The three-slot ring runs two ray tiles ahead of the MFMAs
-    // ACROSS k-steps: the last two tiles of a step already ask for the first two fragments of the next one (stamps
-    // showed a wave that restarts the ring every k-step, waiting out one LDS round trip in front of 30 MFMAs, keeping
-    // the matrix pipe only 56 % busy when it has it to itself). Tile m of every step uses slot m % kRing, and kRing
-    // divides MT (3 slots for 6 tiles, 4 for 4), so the slots - the registers - of a tile are the same in every step.
-    const uint32_t xAddr0 = (uint32_t)(uintptr_t)X + ((rowBase + (lane & 15)) * stride + L.inBase + ((8 * (lane >> 4)) ^ nif_swizzle(lane))) * 2u;
-    const uint32_t mStep = 16u * stride * 2u;
+    constexpr uint32_t kStepBytes = ROWS * 64u;      // one k-chunk of the image
+    const uint32_t xLane = (uint32_t)(uintptr_t)X + nif_x_byte<ROWS>(rowBase + (lane & 15), L.inBase + 8 * (lane >> 4));
     constexpr uint32_t kRing = (MT % 3u == 0u) ? 3u : 4u;
     static_assert(MT % kRing == 0 && MT >= 2, "the activation ring runs two tiles ahead and must divide the tiles of a step");
     h8 xb[kRing];
-    auto readX = [&](h8& x, uint32_t addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(x) : "v"(addr)); };
-    auto step = [&](const h8 (&w)[TN], uint32_t ks, auto first) {
-      // B fragment: X^T[k][ray] = X[ray = rowBase + 16m + (lane&15)][k = 32ks + 8(lane>>4) + j]
-      const uint32_t a0 = xAddr0 + 64u * ks;
-      const uint32_t aNext = ks + 1 < kSteps ? a0 + 64u : a0;             // behind the last step: a harmless re-read, retired by the drain
+#if defined(MI_NIF_KO) && (MI_NIF_KO & 2)
+    auto readX = [&](h8& x, uint32_t addr, auto off) { asm volatile("; no read %0, %1" : "+v"(x) : "v"(addr)); };
+#else
+    auto readX = [&](h8& x, uint32_t addr, auto off) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x) : "v"(addr), "n"(decltype(off)::value)); };
+#endif
+    // "all but the newest `younger` loads have landed": the set about to be used (and, the first time, the bias behind it)
+    auto landedBut = [&](h8 (&w)[TN], auto younger) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(younger)::value));
 #pragma unroll
-      for (uint32_t m = 0; m < MT; ++m) {
-        if (m + 2 < MT) readX(xb[(m + 2) % kRing], a0 + (m + 2) * mStep);
-        else readX(xb[(m + 2) % kRing], aNext + (m + 2 - MT) * mStep);
-        asm volatile("s_waitcnt lgkmcnt(2)\n\t; landed %0" : "+v"(xb[m % kRing]));
-        // the first k-step's MFMAs take C = 0; the bias is added in the epilogue. It is not fetched by a load of its
-        // own (a compiler-issued load in front of the hand-counted ones made hipcc drain the whole queue before the
-        // first MFMA of every layer): it rides the weight stream as the fragment behind each tile's last k-step.
+      for (uint32_t a = 0; a < TN; ++a) asm volatile("; landed %0" : "+v"(w[a]));
+    };
+    auto landed = [&](h8 (&w)[TN]) { landedBut(w, std::integral_constant<int, 2 * TN>{}); };
+    // One k-step on the fragment set w. On entry tile 0's fragment has landed and tile 1's is in flight. Per ray tile:
+    //   MFMA 0 | ds_read of tile m+2 (of the next step behind the last two tiles) | MFMAs 1..TN-2 |
+    //   s_waitcnt lgkmcnt(1) = tile m+1 has landed | MFMA TN-1
+    // so the read and the wait issue in the shadow of an MFMA (8 of its 16 cycles leave the issue port free).
+    // Behind the last step the reads fetch the k-chunk after the layer's input: inside the image, or its one chunk of
+    // slack (nif_launch_mlp); the drain retires them.
+    auto step = [&](h8 (&w)[TN], uint32_t ks, auto first) {
+      constexpr bool isFirst = decltype(first)::value;
+      const uint32_t a0 = xLane + ks * kStepBytes;
+      nif_unroll([&](auto mc) {
+        constexpr uint32_t m = decltype(mc)::value;
+        constexpr uint32_t off = (m + 2 < MT) ? (m + 2) * 1024u : kStepBytes + (m + 2 - MT) * 1024u;
 #pragma unroll
-        for (uint32_t a = 0; a < TN; ++a)
-          acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[a], xb[m % kRing], decltype(first)::value ? zero4 : acc[a][m], 0, 0, 0);
+        for (uint32_t a = 0; a < TN; ++a) {
+          if (a + 1 == TN && TN > 1) asm volatile("s_waitcnt lgkmcnt(1)\n\t; landed %0" : "+v"(xb[(m + 1) % kRing]));
+          if (isFirst) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(acc[a][m]) : "v"(w[a]), "v"(xb[m % kRing]), "v"(bv[a]));
+          else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[a][m]) : "v"(w[a]), "v"(xb[m % kRing]));
+          if (a == 0) readX(xb[(m + 2) % kRing], a0, std::integral_constant<uint32_t, off>{});
+          if (TN == 1) asm volatile("s_waitcnt lgkmcnt(1)\n\t; landed %0" : "+v"(xb[(m + 1) % kRing]));
+        }
+      }, std::make_integer_sequence<uint32_t, MT>{});
+      if (isFirst) {
+        // the bias registers were SrcC of MFMAs hipcc does not know about: keep them allocated until those have read them
+        asm volatile("s_nop 7");
+#pragma unroll
+        for (uint32_t a = 0; a < TN; ++a) asm volatile("; keep %0" ::"v"(bv[a]));
       }
     };
-    using TwoSets = std::integral_constant<int, 2 * TN>;
     MI_STAMP(tK0);
-    readX(xb[0], xAddr0);
-    readX(xb[1], xAddr0 + mStep);
+    readX(xb[0], xLane, std::integral_constant<uint32_t, 0>{});
+    readX(xb[1], xLane, std::integral_constant<uint32_t, 1024>{});
+    asm volatile("s_waitcnt lgkmcnt(1)\n\t; landed %0" : "+v"(xb[0]));
     loadW(wB, 1);
-    loadW(wC, 2); landed(wA, TwoSets{}); step(wA, 0, std::true_type{});
-    loadW(wA, 3); landed(wB, TwoSets{}); if (1 < kSteps) step(wB, 1, std::false_type{});
-    loadW(wB, 4); landed(wC, TwoSets{}); if (2 < kSteps) step(wC, 2, std::false_type{});
+    // (the loads and the wait in front of a k-step are issued whether or not the step exists - past the end the last
+    // fragment again - so which registers have a load in flight never depends on the path taken: hipcc chains the
+    // conditional steps with flag registers, and its branch structure contains paths the source rules out. Early exits
+    // instead of conditional steps make it spill ~2000 registers - 120 accumulators x 6 exits meet at the drain - and an
+    // else-branch that issues a skipped step's loads makes it copy sets that are in flight where the branches meet.)
+    // (step 0 runs with two sets and the bias in registers; the third set is asked for once the bias is spent)
+    landedBut(wA, std::integral_constant<int, TN>{});
+#pragma unroll
+    for (uint32_t a = 0; a < TN; ++a) asm volatile("; landed %0" : "+v"(bv[a]));
+    step(wA, 0, std::true_type{});
+    loadW(wC, 2);
+    loadW(wA, 3); landed(wB); if (1 < kSteps) step(wB, 1, std::false_type{});
+    loadW(wB, 4); landed(wC); if (2 < kSteps) step(wC, 2, std::false_type{});
     for (uint32_t ks = 3; ks < kSteps; ks += 3) {
-      loadW(wC, ks + 2); landed(wA, TwoSets{}); step(wA, ks, std::false_type{});
-      loadW(wA, ks + 3); landed(wB, TwoSets{}); if (ks + 1 < kSteps) step(wB, ks + 1, std::false_type{});
-      loadW(wB, ks + 4); landed(wC, TwoSets{}); if (ks + 2 < kSteps) step(wC, ks + 2, std::false_type{});
+      loadW(wC, ks + 2); landed(wA); step(wA, ks, std::false_type{});
+      loadW(wA, ks + 3); landed(wB); if (ks + 1 < kSteps) step(wB, ks + 1, std::false_type{});
+      loadW(wB, ks + 4); landed(wC); if (ks + 2 < kSteps) step(wC, ks + 2, std::false_type{});
     }
-    // drain: the two weight sets and the two activation fragments still in flight own their registers until they land
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
+    // drain: the weight sets and activation fragments still in flight own their registers until they land; the pads
+    // are the wait states between the last MFMAs and the first VALU read of an accumulator (the hazard recogniser does
+    // not see MFMAs inside asm statements)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15");
 #pragma unroll
     for (uint32_t a = 0; a < TN; ++a) { asm volatile("; landed %0" : "+v"(wA[a])); asm volatile("; landed %0" : "+v"(wB[a])); asm volatile("; landed %0" : "+v"(wC[a])); }
 #pragma unroll
     for (uint32_t q = 0; q < kRing; ++q) asm volatile("; landed %0" : "+v"(xb[q]));
-    // the last load into wA was past the end for every kSteps >= 1: it holds the tiles' bias fragments
 #pragma unroll
-    for (uint32_t a = 0; a < TN; ++a) bv[a] = __builtin_bit_cast(f4v, wA[a]);
+    for (uint32_t a = 0; a < TN; ++a)
+#pragma unroll
+      for (uint32_t m = 0; m < MT; ++m) asm volatile("; result %0" : "+v"(acc[a][m]));
     MI_STAMP(tK1);
     MI_STAMP_ADD(0, tK0, tK1);
   }
@@ -440,12 +486,12 @@ __global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : 1) nif_ml
                                                       const uint32_t* __restrict__ idx, const uint32_t* __restrict__ countPtr,
                                                       uint32_t numRows, float* __restrict__ bgrOut, mi_trace_result* rays, bool scatter) {
   constexpr uint32_t kNifRows = 16u * MT * RG;                    // rays per workgroup pass
-  extern __shared__ __attribute__((aligned(16))) _Float16 X[];   // [kNifRows][P.stride]
+  extern __shared__ __attribute__((aligned(16))) _Float16 X[];   // nif_x_byte<kNifRows>: [P.stride / 32][kNifRows][32] (+ one chunk of slack)
   __shared__ float uvS[2 * kNifRows];                            // the pass's environment coordinates, fetched once
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t ng = wave & 3u, rowBase = 16u * MT * (wave >> 2);   // output-feature group, row group
   const uint32_t total = countPtr ? *countPtr : numRows;
-  const uint32_t stride = P.stride;
+  char* const Xb = reinterpret_cast<char*>(X);
   const uint32_t E = P.embedDim, F = 4 * E;
 #if MI_NIF_STAMPS
   unsigned long long stampSum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -456,10 +502,10 @@ __global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : 1) nif_ml
   // once per pass. Items are numbered column-major (e = column * kNifRows + row) so the row/column split divides by a
   // compile-time constant.
   {
-    const uint32_t padCols = stride - P.featBase - F;
+    const uint32_t padCols = P.stride - P.featBase - F;
     for (uint32_t e = tid; e < kNifRows * padCols; e += blockDim.x) {
       const uint32_t r = e % kNifRows, c = e / kNifRows;
-      X[r * stride + ((P.featBase + F + c) ^ nif_swizzle(r))] = (_Float16)0.f;
+      *reinterpret_cast<_Float16*>(Xb + nif_x_byte<kNifRows>(r, P.featBase + F + c)) = (_Float16)0.f;
     }
   }
   // Two row groups (RG == 2) run HALF A PHASE APART: the second group passes one extra barrier here and the first one
@@ -498,8 +544,8 @@ __global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : 1) nif_ml
       sincos_half_phase(phase, fs, fc);
       const _Float16 sn = (_Float16)fs, cs = (_Float16)fc;
       // feature order [sin u | sin v | cos u | cos v] (NifModel.cpp:216)
-      X[r * stride + ((P.featBase + q) ^ nif_swizzle(r))] = sn;
-      X[r * stride + ((P.featBase + 2 * E + q) ^ nif_swizzle(r))] = cs;
+      *reinterpret_cast<_Float16*>(Xb + nif_x_byte<kNifRows>(r, P.featBase + q)) = sn;
+      *reinterpret_cast<_Float16*>(Xb + nif_x_byte<kNifRows>(r, P.featBase + 2 * E + q)) = cs;
     }
     __syncthreads();
     MI_STAMP(tS1);
@@ -517,8 +563,8 @@ __global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : 1) nif_ml
 #else
 #define MI_NIF_STAMP_ARG
 #endif
-#define MI_NIF_RUN(TN) do { if (finalLayer) nif_dense_layers<TN, MT, true>(P, l, l1, X, stride, rowBase, ng, lane, weights, bias, row0, total, idx, bgrOut, rays, scatter MI_NIF_STAMP_ARG); \
-                            else nif_dense_layers<TN, MT, false>(P, l, l1, X, stride, rowBase, ng, lane, weights, bias, row0, total, idx, bgrOut, rays, scatter MI_NIF_STAMP_ARG); } while (0)
+#define MI_NIF_RUN(TN) do { if (finalLayer) nif_dense_layers<TN, MT, kNifRows, true>(P, l, l1, X, rowBase, ng, lane, weights, bias, row0, total, idx, bgrOut, rays, scatter MI_NIF_STAMP_ARG); \
+                            else nif_dense_layers<TN, MT, kNifRows, false>(P, l, l1, X, rowBase, ng, lane, weights, bias, row0, total, idx, bgrOut, rays, scatter MI_NIF_STAMP_ARG); } while (0)
       if (tilesLayer == TILES) MI_NIF_RUN(TILES);
       if constexpr (TILES > 1) { if (tilesLayer == 1) MI_NIF_RUN(1); }
       if constexpr (TILES > 2) { if (tilesLayer == 2) MI_NIF_RUN(2); }
@@ -548,9 +594,11 @@ inline void nif_launch_mlp(const NifDevice& nif, const float* u, const float* v,
   // pressure hipcc spills around the hand-counted asm loads, which the .s audit in tests/ flags.)
   uint32_t mt = 6, rg = 1;
   if (shape != 0) { rg = 2; mt = (shape == 1) ? 6 : 4; }
-  if (!(mt == 4 && rg == 2) && ((size_t)16 * mt * rg * nif.p.stride * sizeof(_Float16) > kNifMaxLdsBytes || maxTiles > 5)) { mt = 4; rg = 2; }
+  // the image plus one k-chunk of slack: the activation ring of a layer's last k-step reads one chunk past its input
+  auto imageBytes = [&](uint32_t rows) { return (size_t)rows * (nif.p.stride + 32u) * sizeof(_Float16); };
+  if (!(mt == 4 && rg == 2) && (imageBytes(16 * mt * rg) > kNifMaxLdsBytes || maxTiles > 5)) { mt = 4; rg = 2; }
   auto launch = [&](auto kern, uint32_t rowsPerPass, uint32_t threads) {
-    size_t lds = (size_t)rowsPerPass * nif.p.stride * sizeof(_Float16);
+    size_t lds = imageBytes(rowsPerPass);
 #if MI_NIF_STAMPS
     if (getenv("MI_NIF_DIAG_ONE_WG")) lds = kNifMaxLdsBytes;   // diagnostic: one workgroup per CU, i.e. one wave per SIMD for the 4-wave shape
 #endif
