@@ -291,3 +291,51 @@ def test_headers_are_plain_c99(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", str(ROOT / "include"), "-fsyntax-only", str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_nif_activation_image_layout_is_conflict_free():
+    """csrc/nif_kernels.hpp nif_x_byte: the k-chunk-major, piece-swapped LDS image of K3. Re-stated here (the formula is
+    read out of the header, so the two cannot drift apart) and enumerated against the LDS rules of
+    MI355X_MICROARCH.md: every 16-lane group of a ds_read_b128 B-fragment read hits 16 different 4-bank slots of the
+    64-bank row, the epilogue's ds_write_b64 (16 consecutive lanes, 32-bank rule) is at most 2-way, and the map is a
+    bijection onto [0, rows * columns * 2)."""
+    src = (Path(irl.__file__).parent / "csrc" / "nif_kernels.hpp").read_text()
+    m = re.search(r"const uint32_t sw = \(0x([0-9a-fA-F]+)u >> \(2u \* \(\(ray >> 2\) & 3u\)\)\) & 3u;", src)
+    assert m, "nif_x_byte changed: update this test"
+    packed = int(m.group(1), 16)
+    assert "return (col >> 5) * (ROWS * 64u) + ray * 64u + ((((col >> 3) & 3u) ^ sw) << 4) + (col & 7u) * 2u;" in src
+
+    def xbyte(rows, ray, col):
+        sw = (packed >> (2 * ((ray >> 2) & 3))) & 3
+        return (col >> 5) * (rows * 64) + ray * 64 + ((((col >> 3) & 3) ^ sw) << 4) + (col & 7) * 2
+
+    read_groups = [[*range(0, 4), *range(12, 16), *range(20, 28)], [*range(4, 12), *range(16, 20), *range(28, 32)],
+                   [*range(32, 36), *range(44, 48), *range(52, 60)], [*range(36, 44), *range(48, 52), *range(60, 64)]]
+    for rows in (96, 128, 192):
+        for ks in range(12):
+            for mt in range(rows // 16):
+                for grp in read_groups:            # B fragment: lane l reads 16 bytes of ray 16m + (l & 15), columns 32ks + 8(l >> 4)..
+                    banks = {}
+                    for lane in grp:
+                        dw = xbyte(rows, 16 * mt + (lane & 15), 32 * ks + 8 * (lane >> 4)) // 4
+                        for d in range(4):
+                            banks.setdefault((dw + d) % 64, set()).add(dw + d)
+                    assert max(len(v) for v in banks.values()) == 1, (rows, ks, mt)
+        for nt in range(20):
+            for mt in range(rows // 16):
+                for g0 in range(0, 64, 16):        # D fragment store: lane l writes 8 bytes of ray 16m + (l & 15), columns 16nt + 4(l >> 4)..
+                    banks = {}
+                    for lane in range(g0, g0 + 16):
+                        dw = xbyte(rows, 16 * mt + (lane & 15), 16 * nt + 4 * (lane >> 4)) // 4
+                        for d in range(2):
+                            banks.setdefault((dw + d) % 32, set()).add(dw + d)
+                    assert max(len(v) for v in banks.values()) <= 2, (rows, nt, mt)
+        cols = 384
+        seen = {xbyte(rows, r, c) for r in range(rows) for c in range(cols)}
+        assert len(seen) == rows * cols and min(seen) == 0 and max(seen) == rows * cols * 2 - 2
+        # the compile-time offsets of the k-loop: a ray tile is 1 KiB on, a k-step one chunk (rows x 64 B) on
+        for lane in range(64):
+            base = xbyte(rows, lane & 15, 8 * (lane >> 4))
+            for ks in range(12):
+                for mt in range(rows // 16):
+                    assert xbyte(rows, 16 * mt + (lane & 15), 32 * ks + 8 * (lane >> 4)) == base + ks * rows * 64 + mt * 1024
