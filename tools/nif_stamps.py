@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Where one wave of K3 spends its cycles (diagnostic build: hipcc ... -DMI_NIF_STAMPS=1 -o build/ab/lib_stamps.so,
 run with MI_RAYLIB_LIB=build/ab/lib_stamps.so). Prints the shares of the s_memtime brackets in nif_kernels.hpp summed
-over the second wave of every workgroup's row groups; the build's run time itself is not a measurement."""
+over the second wave of every workgroup's row groups; the build's run time itself is not a measurement.
+MI_NIF_DIAG_ONE_WG=1 (stamp builds only) asks for the whole LDS, i.e. one workgroup per CU = one wave per SIMD for the
+4-wave shape. -DMI_NIF_KO=1|2|3 builds knock the weight loads (1) / the LDS reads (2) out of the k-loop (wrong results:
+timing and stamps only) to price them."""
 import ctypes as C, json, sys
 from pathlib import Path
 import numpy as np
