@@ -222,8 +222,13 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
       need(d.mesh_tris[3 * (size_t)mi_.first_index + t] < mi_.num_vertices, "triangle vertex index out of range");
   }
 
-  // Node array: box widened to six floats, interior link := skip index (preorder subtree end). Also checks that the
-  // array really is a preorder BVH2 (first child adjacent, second child after it, every node reached).
+  // Node array: box widened to six floats, link := next(i), the node that follows i's subtree in preorder (interior
+  // nodes: instead of the second child's index; leaves: beside their primitive). Also checks that the array really is a
+  // preorder BVH2 (first child adjacent, second child after it, every node reached).
+  // (With `next` explicit the device array only has to keep "first child = i + 1". Laying the chains of first children
+  // out by falling surface area puts 93 % of the box scene's node visits into the first 128 of its 8 069 nodes - in
+  // preorder the first 1 024 take 38 % - and serving that prefix from LDS was measured: 4.5 % SLOWER than the L1 that
+  // already holds it; the array stays in preorder.)
   const uint32_t N = d.num_nodes;
   std::vector<GNode> nodes(N);
   std::vector<uint32_t> skip(N);
@@ -252,9 +257,9 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
     g.maxx = n.min_x + half_bits_to_float(n.dx);                  // CompactBVH2Node.cpp:8-10, one rounded add each
     g.maxy = n.min_y + half_bits_to_float(n.dy);
     g.maxz = n.min_z + half_bits_to_float(n.dz);
-    g.geomID = n.geom_id;
-    if (n.geom_id == MI_INVALID_GEOM) g.link = skip[i];
-    else {
+    g.link = skip[i];
+    g.leaf = kInteriorNode;
+    if (n.geom_id != MI_INVALID_GEOM) {
       need(n.geom_id < d.num_geometry, "leaf geomID out of range");
       const mi_geom_ref& r = d.geometry[n.geom_id];
       GLeaf L;
@@ -281,7 +286,7 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
         L.type = LEAF_DISC | ((uint32_t)n.geom_id << 16); L.primID = 0;
       }
       L.matIndex = d.mat_ids[n.geom_id];
-      g.link = (uint32_t)leaves.size();
+      g.leaf = (uint32_t)leaves.size();
       leaves.push_back(L);
     }
     nodes[i] = g;

@@ -5,11 +5,11 @@
 // Traversal design. The reference walks the depth-first CompactBVH2Node array with a
 // per-ray stack, always first child first (CompactBvh.hpp:80-139). Because the array is in
 // preorder, "pop the next entry" is always the node that follows the current node's subtree, so the
-// same visit order is produced by a STACKLESS walk: box hit on an interior node -> i+1, anything
-// else -> skip(i) where skip(i) = i + subtree size (i+1 for leaves). The upload step rewrites the
-// interior nodes' link word from secondChildIndex to that skip index; no per-wavefront stack, no
-// LDS or scratch traffic for it, and every lane's sequence of box tests, primitive tests and
-// closest-hit updates is exactly the reference's.
+// same visit order is produced by a STACKLESS walk: box hit on an interior node -> its first child,
+// anything else -> next(i), the node that follows i's subtree in preorder. The upload step gives every
+// device node that `next` explicitly (interior nodes: instead of secondChildIndex; leaves: beside their
+// primitive's index); no per-wavefront stack, no LDS or scratch traffic for it, and every lane's
+// sequence of box tests, primitive tests and closest-hit updates is exactly the reference's.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -27,9 +27,10 @@ namespace mi {
 // a 64-bit register pair feeds the packed subtract/multiply directly.
 struct __attribute__((aligned(16))) GNode {
   float minx, maxx, miny, maxy, minz, maxz;
-  uint32_t link;                                  // interior: skip index; leaf: index into leaves[]
-  uint32_t geomID;                                // 0xFFFF = interior
+  uint32_t link;                                  // next(i): where the walk goes on when it does not descend (numNodes = it ends)
+  uint32_t leaf;                                  // index into leaves[]; 0xFFFFFFFF = interior node (its first child is i + 1)
 };
+constexpr uint32_t kInteriorNode = 0xFFFFFFFFu;
 static_assert(sizeof(GNode) == 32, "GNode must stay 32 bytes");
 
 enum : uint32_t { LEAF_TRI = 0, LEAF_SPHERE = 1, LEAF_DISC = 2 };
@@ -224,10 +225,10 @@ __device__ __forceinline__ bool traverse(const DeviceScene& sc, f3 o, f3 d, floa
       t1 = tmax < t1 ? tmax : t1;
     }
     const bool boxHit = !(t0 > t1);
-    const bool isLeaf = nd.geomID != 0xFFFFu;
+    const bool isLeaf = nd.leaf != kInteriorNode;
     if (boxHit && isLeaf) {
       if (STATS) cs.leaves++;
-      const GLeaf L = sc.leaves[nd.link];
+      const GLeaf L = sc.leaves[nd.leaf];
       float t, b0 = 0.f, b1 = 0.f, b2 = 0.f;
       bool cand;
       if (leaf_kind(L) == LEAF_TRI) {
@@ -242,11 +243,11 @@ __device__ __forceinline__ bool traverse(const DeviceScene& sc, f3 o, f3 d, floa
       }
       if (cand && t > tMin && t < hit.t) {          // CompactBvh.hpp:124 / :60 (hit.t == ray.tMax for any-hit)
         if (ANY_HIT) return true;
-        hit.t = t; hit.leaf = nd.link; hit.geomID = nd.geomID; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2;
+        hit.t = t; hit.leaf = nd.leaf; hit.geomID = leaf_geom(L); hit.b0 = b0; hit.b1 = b1; hit.b2 = b2;
       }
     }
     // next node in the reference's visit order
-    i = (boxHit && !isLeaf) ? i + 1 : (isLeaf ? i + 1 : nd.link);
+    i = (boxHit && !isLeaf) ? i + 1 : nd.link;
   }
   return hit.leaf != 0xFFFFFFFFu;
 }

@@ -254,10 +254,10 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES_PER_SIMD) path_trace_pool_ke
           }
         }
         const bool boxHit = !(t0 > t1);
-        const bool isLeaf = nd.geomID != 0xFFFFu;
-        pendLeaf = nd.link;
+        const bool isLeaf = nd.leaf != kInteriorNode;
+        pendLeaf = nd.leaf;
+        node = (boxHit && !isLeaf) ? node + 1 : nd.link;          // (a lane that waits for a primitive test already stands at the node behind it)
         if (boxHit && isLeaf) { ph = PP_LEAF; return false; }
-        node = (boxHit || isLeaf) ? node + 1 : nd.link;
         if (node >= numNodes) { ph = PP_FIN; return false; }
         return true;
       };
@@ -305,7 +305,6 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES_PER_SIMD) path_trace_pool_ke
               cand = true;
             }
             if (cand && t > 0.f && t < hit.t) { hit.t = t; hit.leaf = pendLeaf; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2; }
-            node = node + 1;
             ph = (node >= numNodes) ? PP_FIN : PP_NODE;
           }
           if (tune.leafThenNode) {

@@ -244,26 +244,26 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
             }
           }
           const bool boxHit = !(t0 > t1);
-          const bool isLeaf = nd.geomID != 0xFFFFu;
+          const bool isLeaf = nd.leaf != kInteriorNode;
           if (SPEC) {
             if (STATS) { if (pend1 != 0xFFFFFFFFu) { cs.nodes--; specNodes++; } }
+            node = (boxHit && !isLeaf) ? node + 1 : nd.link;      // (a lane always stands at the node BEHIND a primitive it waits for; pend1Node likewise)
             if (boxHit && isLeaf) {
-              if (pend1 != 0xFFFFFFFFu) { pendLeaf = nd.link; ph = PH_LEAF; return false; }     // a second one: wait
-              pend1 = nd.link; pend1Node = node;                                                // the first one: walk on
+              if (pend1 != 0xFFFFFFFFu) { pendLeaf = nd.leaf; ph = PH_LEAF; return false; }     // a second one: wait
+              pend1 = nd.leaf; pend1Node = node;                                                // the first one: walk on
             }
-            node = (boxHit || isLeaf) ? node + 1 : nd.link;
             if (node >= numNodes) {
               if (pend1 != 0xFFFFFFFFu) { pendLeaf = 0xFFFFFFFFu; ph = PH_LEAF; } else ph = PH_SHADE;   // walked to the end with a test pending: wait for it
               return false;
             }
             return true;
           }
-          pendLeaf = nd.link;          // only read while the lane is in PH_LEAF; assigned for every lane so that no merge copy is needed
+          pendLeaf = nd.leaf;          // only read while the lane is in PH_LEAF; assigned for every lane so that no merge copy is needed
+          node = (boxHit && !isLeaf) ? node + 1 : nd.link;      // (a lane that waits for a primitive test already stands at the node behind it)
           if (boxHit && isLeaf) {
             ph = PH_LEAF;
             return false;
           }
-          node = (boxHit || isLeaf) ? node + 1 : nd.link;
           if (node >= numNodes) { ph = PH_SHADE; return false; }
           return true;
         }
@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
               if (cand && t > 0.f && t < hit.t) {
                 // a closer hit: everything walked since is void, the walk resumes behind the primitive's node with it
                 hit.t = t; hit.leaf = pend1; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2;
-                node = pend1Node + 1;
+                node = pend1Node;
                 pend1 = 0xFFFFFFFFu;
                 if (STATS) specNodes = 0;
                 ph = (node >= numNodes) ? PH_SHADE : PH_NODE;
@@ -336,7 +336,6 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
                 if (ph == PH_LEAF) {
                   if (pendLeaf != 0xFFFFFFFFu) {             // the second primitive becomes the pending one, the walk goes on
                     pend1 = pendLeaf; pend1Node = node;
-                    node = node + 1;
                     if (node >= numNodes) pendLeaf = 0xFFFFFFFFu; else ph = PH_NODE;
                   } else ph = PH_SHADE;                      // the walk had already reached the end
                 }
@@ -360,7 +359,6 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
               cand = true;
             }
             if (cand && t > 0.f && t < hit.t) { hit.t = t; hit.leaf = pendLeaf; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2; }
-            node = node + 1;
             ph = (node >= numNodes) ? PH_SHADE : PH_NODE;
           }
           // every lane that waited for a primitive test is walking again: the next vote would pick NODE anyway,
