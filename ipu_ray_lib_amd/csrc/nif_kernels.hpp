@@ -61,6 +61,7 @@ __device__ __forceinline__ unsigned long long nif_now() {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));   // a 16-byte fragment as the asm statements of the k-loop see it (legal as an in/out operand; 8 halves are not)
 
 // Workgroup shapes of the same kernel (template parameters MT = 16-ray tiles per wave, RG = row groups):
 //   w6 (default) : 4 waves x 96 rays, two workgroups per CU; every packed weight fragment is fetched once per
@@ -356,14 +357,18 @@ __device__ __forceinline__ void nif_dense_layers(const NifParams& P, uint32_t l0
     // waits are free only while they sit BETWEEN MFMAs. Stamps (tools/nif_stamps.py) showed a lone wave's k-loop at
     // 1.7x its MFMA time with the compiler's placement (loads and five scalar instructions of address arithmetic each
     // bunched in front of a k-step, a v_add per LDS read, s_nop pads behind every "landed" marker).
-    //   weight stream : three fragment sets; the set of k-step ks+2 is asked for in front of step ks (TN loads behind
-    //                   two instructions of address arithmetic); "all but the newest 2*TN loads have landed" (loads
-    //                   return in order) is the set about to be used - and, in step 0, the bias.
+    //   weight stream : three fragment sets; a step asks for its OWN set's next fragments (k-step ks+3) in its last ray
+    //                   tile, each load in the shadow of the MFMA that was the last to read that fragment (a
+    //                   global_load_dwordx4 holds the issue port for ~16 cycles: five of them in front of a step cost 80
+    //                   of its 480); "all but the newest 2*TN loads have landed" (loads return in order) is the set
+    //                   about to be used - and, in step 0, the bias. A skipped tail step skips its loads too; the
+    //                   waits in front of the steps are unconditional, so every set a later step could read has landed
+    //                   on every path hipcc's branch structure contains.
     //   activations   : a ring of LDS reads two ray tiles ahead, across k-steps (the last two tiles of a step ask for
     //                   the first two fragments of the next); tile m of every step uses slot m % kRing, kRing divides MT.
     // Every destination is named behind its wait ("; landed vN") for tests/test_asm_pipeline_audit.py, which checks
     // that nothing touches a destination in flight and that no store / atomic / scratch access joins the counted queue.
-    h8 wA[TN], wB[TN], wC[TN];
+    u4v wA[TN], wB[TN], wC[TN];
     f4v bv[TN];
     uint64_t wTile[TN];
 #pragma unroll
@@ -374,12 +379,12 @@ __device__ __forceinline__ void nif_dense_layers(const NifParams& P, uint32_t l0
       wTile[a] = (uint64_t)(uintptr_t)(weights + L.wOffset) + off;
     }
 #if defined(MI_NIF_KO) && (MI_NIF_KO & 1)
-    auto loadOne = [&](h8& w, uint32_t voff, uint32_t a) { asm volatile("; no load %0, %1, %2" : "+v"(w) : "v"(voff), "s"(wTile[a])); };
+    auto loadOne = [&](u4v& w, uint32_t voff, uint32_t a) { asm volatile("; no load %0, %1, %2" : "+v"(w) : "v"(voff), "s"(wTile[a])); };
 #else
-    auto loadOne = [&](h8& w, uint32_t voff, uint32_t a) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(w) : "v"(voff), "s"(wTile[a])); };
+    auto loadOne = [&](u4v& w, uint32_t voff, uint32_t a) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(w) : "v"(voff), "s"(wTile[a])); };
 #endif
     auto fragOff = [&](uint32_t ks) { return laneOff + ((1u + (ks < kSteps ? ks : kSteps - 1u)) << 10); };   // past the end: the last fragment again (keeps the count uniform)
-    auto loadW = [&](h8 (&w)[TN], uint32_t ks) {
+    auto loadW = [&](u4v (&w)[TN], uint32_t ks) {
       const uint32_t voff = fragOff(ks);
 #pragma unroll
       for (uint32_t a = 0; a < TN; ++a) loadOne(w[a], voff, a);
@@ -394,28 +399,29 @@ __device__ __forceinline__ void nif_dense_layers(const NifParams& P, uint32_t l0
     const uint32_t xLane = (uint32_t)(uintptr_t)X + nif_x_byte<ROWS>(rowBase + (lane & 15), L.inBase + 8 * (lane >> 4));
     constexpr uint32_t kRing = (MT % 3u == 0u) ? 3u : 4u;
     static_assert(MT % kRing == 0 && MT >= 2, "the activation ring runs two tiles ahead and must divide the tiles of a step");
-    h8 xb[kRing];
+    u4v xb[kRing];
 #if defined(MI_NIF_KO) && (MI_NIF_KO & 2)
-    auto readX = [&](h8& x, uint32_t addr, auto off) { asm volatile("; no read %0, %1" : "+v"(x) : "v"(addr)); };
+    auto readX = [&](u4v& x, uint32_t addr, auto off) { asm volatile("; no read %0, %1" : "+v"(x) : "v"(addr)); };
 #else
-    auto readX = [&](h8& x, uint32_t addr, auto off) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x) : "v"(addr), "n"(decltype(off)::value)); };
+    auto readX = [&](u4v& x, uint32_t addr, auto off) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x) : "v"(addr), "n"(decltype(off)::value)); };
 #endif
     // "all but the newest `younger` loads have landed": the set about to be used (and, the first time, the bias behind it)
-    auto landedBut = [&](h8 (&w)[TN], auto younger) {
+    auto landedBut = [&](u4v (&w)[TN], auto younger) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(younger)::value));
 #pragma unroll
       for (uint32_t a = 0; a < TN; ++a) asm volatile("; landed %0" : "+v"(w[a]));
     };
-    auto landed = [&](h8 (&w)[TN]) { landedBut(w, std::integral_constant<int, 2 * TN>{}); };
+    auto landed = [&](u4v (&w)[TN]) { landedBut(w, std::integral_constant<int, 2 * TN>{}); };
     // One k-step on the fragment set w. On entry tile 0's fragment has landed and tile 1's is in flight. Per ray tile:
     //   MFMA 0 | ds_read of tile m+2 (of the next step behind the last two tiles) | MFMAs 1..TN-2 |
     //   s_waitcnt lgkmcnt(1) = tile m+1 has landed | MFMA TN-1
     // so the read and the wait issue in the shadow of an MFMA (8 of its 16 cycles leave the issue port free).
     // Behind the last step the reads fetch the k-chunk after the layer's input: inside the image, or its one chunk of
     // slack (nif_launch_mlp); the drain retires them.
-    auto step = [&](h8 (&w)[TN], uint32_t ks, auto first) {
+    auto step = [&](u4v (&w)[TN], uint32_t ks, auto first) {
       constexpr bool isFirst = decltype(first)::value;
       const uint32_t a0 = xLane + ks * kStepBytes;
+      const uint32_t voff3 = fragOff(ks + 3);
       nif_unroll([&](auto mc) {
         constexpr uint32_t m = decltype(mc)::value;
         constexpr uint32_t off = (m + 2 < MT) ? (m + 2) * 1024u : kStepBytes + (m + 2 - MT) * 1024u;
@@ -424,6 +430,9 @@ __device__ __forceinline__ void nif_dense_layers(const NifParams& P, uint32_t l0
           if (a + 1 == TN && TN > 1) asm volatile("s_waitcnt lgkmcnt(1)\n\t; landed %0" : "+v"(xb[(m + 1) % kRing]));
           if (isFirst) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(acc[a][m]) : "v"(w[a]), "v"(xb[m % kRing]), "v"(bv[a]));
           else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[a][m]) : "v"(w[a]), "v"(xb[m % kRing]));
+          // the step's last MFMA on fragment a frees it: its successor three k-steps on is asked for at once, in that
+          // MFMA's shadow ("+v": the same registers, so no copy where a conditional step's branches meet)
+          if (!isFirst && m + 1 == MT) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(w[a]) : "v"(voff3), "s"(wTile[a]));
           if (a == 0) readX(xb[(m + 2) % kRing], a0, std::integral_constant<uint32_t, off>{});
           if (TN == 1) asm volatile("s_waitcnt lgkmcnt(1)\n\t; landed %0" : "+v"(xb[(m + 1) % kRing]));
         }
@@ -451,12 +460,14 @@ __device__ __forceinline__ void nif_dense_layers(const NifParams& P, uint32_t l0
     for (uint32_t a = 0; a < TN; ++a) asm volatile("; landed %0" : "+v"(bv[a]));
     step(wA, 0, std::true_type{});
     loadW(wC, 2);
-    loadW(wA, 3); landed(wB); if (1 < kSteps) step(wB, 1, std::false_type{});
-    loadW(wB, 4); landed(wC); if (2 < kSteps) step(wC, 2, std::false_type{});
+    loadW(wA, 3);
+    // from here on every step asks for its own set's next fragments (k-step ks + 3) behind its last ray tile's MFMAs
+    landed(wB); if (1 < kSteps) step(wB, 1, std::false_type{});
+    landed(wC); if (2 < kSteps) step(wC, 2, std::false_type{});
     for (uint32_t ks = 3; ks < kSteps; ks += 3) {
-      loadW(wC, ks + 2); landed(wA); step(wA, ks, std::false_type{});
-      loadW(wA, ks + 3); landed(wB); if (ks + 1 < kSteps) step(wB, ks + 1, std::false_type{});
-      loadW(wB, ks + 4); landed(wC); if (ks + 2 < kSteps) step(wC, ks + 2, std::false_type{});
+      landed(wA); step(wA, ks, std::false_type{});
+      landed(wB); if (ks + 1 < kSteps) step(wB, ks + 1, std::false_type{});
+      landed(wC); if (ks + 2 < kSteps) step(wC, ks + 2, std::false_type{});
     }
     // drain: the weight sets and activation fragments still in flight own their registers until they land; the pads
     // are the wait states between the last MFMAs and the first VALU read of an accumulator (the hazard recogniser does
