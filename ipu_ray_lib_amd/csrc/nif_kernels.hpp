@@ -350,6 +350,9 @@ __device__ __forceinline__ void nif_dense_layers(const NifParams& P, uint32_t l0
   for (uint32_t l = l0; l < l1; ++l) {
     const NifLayerDesc L = P.layers[l];
     const uint32_t kSteps = L.kSteps;
+    // the network's final layer has 3 outputs: one real tile, padded to four so that every wave has one. The three
+    // waves whose tile is padding skip its k-loop (60 MFMAs and 10 KiB of weights each) and only keep the barriers
+    if (LAST && 16 * ng >= L.n) continue;
     // The k-loop is written instruction by instruction (every statement below is a volatile asm, which hipcc keeps in
     // program order; it only allocates the registers and adds the little address arithmetic that is left). Why: a
     // wave issues about one instruction per four cycles, a v_mfma_f32_16x16x32_f16 occupies the matrix pipe for 16 and
