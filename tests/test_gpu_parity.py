@@ -463,6 +463,38 @@ def test_nif_mlp_against_oracle(scenes, shape):
     dev.close()
 
 
+@pytest.mark.parametrize("hidden,layers", [(32, 2), (64, 3), (96, 2), (160, 5), (224, 3), (256, 4), (320, 3), (352, 3), (384, 2)])
+def test_nif_mlp_shapes_against_oracle(scenes, hidden, layers):
+    """The MLP kernel's layer runs over networks of other shapes than the reference's: 1...6 output-feature tiles per
+    wave (352 and 384 take the 8-wave fallback shape), every remainder of the k-step count against the k-loop's
+    three-fold unrolling (first layer 2 k-steps; hidden / concat layers 1, 3, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14), a
+    hidden layer without ReLU and one without bias. Same tolerance as test_nif_mlp_against_oracle."""
+    import torch
+    rng = np.random.default_rng(1000 + hidden + layers)
+    ks, bs, relu = _nif_weights(rng, hidden=hidden, layers=layers)
+    relu[len(relu) // 2] = 0 if len(relu) > 2 else relu[len(relu) // 2]      # a linear hidden layer (the last one is linear anyway)
+    bs[0] = None if hidden % 64 == 0 else bs[0]                                 # Dense(use_bias=False)
+    mean = np.array([-2.35, -2.27, -1.96], np.float32)
+    maxv = 3.43
+    s = scenes["spheres"]
+    dev = irl.IpuScene(s.desc)
+    dev.setNif(ks, bs, relu, 12, maxv, mean, True)
+    n = 3000 + 53
+    u = rng.random(n).astype(np.float32); v = rng.random(n).astype(np.float32)
+    du, dv = torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda()
+    out = torch.zeros(n, 3, device="cuda")
+    dev.nif_infer_device(du.data_ptr(), dv.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    nif, keep = ol.make_nif(ks, bs, relu, 12, maxv, mean, True, half_features=True, half_weights_acts=True)
+    want = np.zeros((n, 3), np.float32)
+    ol.lib().o_nif_infer(C.byref(nif), u.ctypes.data, v.ctypes.data, n, want.ctypes.data)
+    assert np.isfinite(got).all()
+    err = np.abs(got - want) / (np.abs(want) + 1e-3 / 0.02)
+    assert np.quantile(err, 0.999) < 0.02 and err.max() < 0.10, (hidden, layers, np.quantile(err, 0.999), err.max())
+    dev.close()
+
+
 def test_config5_monkey_with_nif_environment():
     """BASELINE config 5 scene (monkey bust, open environment, NIF-shaped 6x320 MLP with synthetic weights) at
     reduced size/spp. Hit records bit exact, rgb within the MLP tolerance."""
