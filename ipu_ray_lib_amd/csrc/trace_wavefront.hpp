@@ -80,6 +80,16 @@ template <bool STATS, bool LDS_NODES, int BLOCK, int WAVES_PER_SIMD = 4, bool SP
 __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? WAVES_PER_SIMD : 1) path_trace_wavefront_kernel(DeviceScene sc, mi_trace_result* rays, uint32_t n,
                                                                    uint32_t* workCounter, uint32_t ldsNodeCount, WaveTune tune, uint32_t tileStreamW, WaveExtras ex) {
   __shared__ float sinTbl[92];
+  // the materials a hit is shaded with, when the scene has few (the built-in scenes have 8, test_scene.dae 9): SHADE
+  // otherwise waits for two dependent global loads, leaf record then material
+  constexpr uint32_t kMatCache = 16;
+  struct __attribute__((aligned(16))) CachedMaterial { mi_material m; uint32_t pad[3]; };
+  __shared__ CachedMaterial matS[kMatCache];
+  const bool matsInLds = sc.numMaterials <= kMatCache;
+  if (matsInLds) {
+    for (uint32_t k = threadIdx.x; k < sc.numMaterials * 9u; k += blockDim.x)
+      reinterpret_cast<uint32_t*>(&matS[k / 9u].m)[k % 9u] = reinterpret_cast<const uint32_t*>(sc.materials)[k];
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned char dynLds[];
   load_sin_table(sinTbl);
   const GNode* ldsNodes = reinterpret_cast<const GNode*>(dynLds);
@@ -390,7 +400,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
           coldU(6) = hit.leaf; coldF(7) = hit.t;
           o = o + d * hit.t;                                          // updateHit, Render.hpp:15-23
           nrm = hit_normal(sc, hit, o);
-          const mi_material mat = sc.materials[L.matIndex];           // = materials[matIDs[geomID]]
+          const mi_material mat = matsInLds ? matS[L.matIndex].m : sc.materials[L.matIndex];           // = materials[matIDs[geomID]]
           const f3 albedo = mk(mat.albedo.x, mat.albedo.y, mat.albedo.z);
           if (mat.emissive) color = color + tp * mk(mat.emission.x, mat.emission.y, mat.emission.z);
           if (mat.type == 0) {
