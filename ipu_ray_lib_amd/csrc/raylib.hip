@@ -299,7 +299,21 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
   ds.materials = S.keep(upload(std::vector<mi_material>(d.materials, d.materials + d.num_materials)));
   ds.numMaterials = d.num_materials;
   ds.hasNormals = d.num_normals ? 1u : 0u;
+  ds.leafNormals = nullptr;
   if (ds.hasNormals) {
+    std::vector<float> ln(9 * leaves.size(), 0.f);
+    for (size_t k = 0; k < leaves.size(); ++k) {
+      const GLeaf& L = leaves[k];
+      if (leaf_kind(L) != LEAF_TRI) continue;
+      const uint32_t fv = geomFirstVertex[leaf_geom(L)];
+      for (int c = 0; c < 3; ++c) {
+        const size_t at = (size_t)fv + d.mesh_tris[L.triBase + c];
+        need(at < d.num_normals, "vertex normal index out of range");
+        const mi_vec3& nn = d.mesh_normals[at];
+        ln[9 * k + 3 * c] = nn.x; ln[9 * k + 3 * c + 1] = nn.y; ln[9 * k + 3 * c + 2] = nn.z;
+      }
+    }
+    ds.leafNormals = S.keep(upload(ln));
     ds.meshTris = S.keep(upload(std::vector<uint16_t>(d.mesh_tris, d.mesh_tris + 3 * (size_t)d.num_tris)));
     ds.meshNormals = S.keep(upload(std::vector<mi_vec3>(d.mesh_normals, d.mesh_normals + d.num_normals)));
     ds.geomFirstVertex = S.keep(upload(geomFirstVertex));

@@ -56,6 +56,7 @@ struct DeviceScene {
   const mi_material* materials; uint32_t numMaterials;
   // vertex normals (only when the scene was loaded with normals)
   const uint16_t* meshTris; const mi_vec3* meshNormals; const uint32_t* geomFirstVertex; uint32_t hasNormals;
+  const float* leafNormals;  // [numLeaves][9]: a triangle leaf's three vertex normals, gathered at upload (zeros for other leaves)
   float imageWidth, imageHeight, tanTheta, antiAliasScale;
   uint32_t maxPathLength, rouletteStartDepth, samplesPerPixel;
   uint64_t rngSeed;
@@ -258,11 +259,10 @@ __device__ __forceinline__ f3 hit_normal(const DeviceScene& sc, const Hit& h, f3
   const GLeaf L = sc.leaves[h.leaf];
   if (leaf_kind(L) == LEAF_TRI) {
     if (!sc.hasNormals) return mk(L.n[0], L.n[1], L.n[2]);
-    const uint32_t fv = sc.geomFirstVertex[h.geomID];
-    const mi_vec3 a = sc.meshNormals[fv + sc.meshTris[L.triBase]];
-    const mi_vec3 b = sc.meshNormals[fv + sc.meshTris[L.triBase + 1]];
-    const mi_vec3 c = sc.meshNormals[fv + sc.meshTris[L.triBase + 2]];
-    return normalized((mk(a.x, a.y, a.z) * h.b0) + (mk(b.x, b.y, b.z) * h.b1) + (mk(c.x, c.y, c.z) * h.b2));
+    // normals[firstVertex + tris[triBase + k]], k = 0..2 (Mesh.hpp:115-120), gathered per leaf at upload: one load
+    // that depends on the leaf's index alone instead of three hops (first vertex, vertex indices, normals)
+    const float* q = sc.leafNormals + 9 * (size_t)h.leaf;
+    return normalized((mk(q[0], q[1], q[2]) * h.b0) + (mk(q[3], q[4], q[5]) * h.b1) + (mk(q[6], q[7], q[8]) * h.b2));
   }
   if (leaf_kind(L) == LEAF_SPHERE) return normalized(hp - mk(L.f[0], L.f[1], L.f[2]));
   return mk(L.f[0], L.f[1], L.f[2]);
