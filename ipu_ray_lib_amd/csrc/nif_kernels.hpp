@@ -13,14 +13,14 @@
 //
 // Kernel shape: a 256-thread workgroup owns 96 rays (two workgroups per CU); wave w evaluates
 // output-feature tiles {w, w+4, ...} for all 96 rays, so every packed weight fragment is fetched once per
-// workgroup and feeds 6 MFMAs. Activations live in LDS as [rays][stride] binary16; the dense layers are
-// evaluated transposed, Y^T = W^T · X^T, so that the MFMA result fragment of a lane is 4 consecutive output
-// features of ONE ray and goes back to LDS as one 8-byte store. W^T is pre-packed on the host in exact
-// A-fragment order, so every weight load is a fully coalesced 1 KiB wave read served from L2. Both operand
-// streams are software-pipelined with inline-asm loads whose completion is counted by hand (hipcc sinks its own
-// loads to their first use at this register pressure): weights three k-steps deep in registers, activation
-// fragments three deep. The 8-wave shapes (64 / 96 rays per row group) are kept selectable (MI_RAYLIB_NIF_SHAPE)
-// for widths whose LDS image does not fit and for the measurements in DESIGN.md.
+// workgroup and feeds 6 MFMAs. Activations live in LDS as a k-chunk-major binary16 image (nif_x_byte); the dense
+// layers are evaluated transposed, Y^T = W^T · X^T, so that the MFMA result fragment of a lane is 4 consecutive
+// output features of ONE ray and goes back to LDS as one 8-byte store. W^T is pre-packed on the host in exact
+// A-fragment order, one stream per 16-feature tile headed by the tile's bias, so every weight load is a fully
+// coalesced 1 KiB wave read served from L2. The k-loop is written instruction by instruction (asm MFMAs, loads, LDS
+// reads and hand-counted waits placed between them: nif_dense_layers); three weight fragment sets and a three-slot
+// activation ring are in flight. The 8-wave shapes (64 / 96 rays per row group) are kept selectable
+// (MI_RAYLIB_NIF_SHAPE) for widths whose LDS image does not fit and for the measurements in DESIGN.md.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -65,7 +65,7 @@ typedef uint32_t u4v __attribute__((ext_vector_type(4)));   // a 16-byte fragmen
 
 // Workgroup shapes of the same kernel (template parameters MT = 16-ray tiles per wave, RG = row groups):
 //   w6 (default) : 4 waves x 96 rays, two workgroups per CU; every packed weight fragment is fetched once per
-//                  workgroup and feeds 6 MFMAs. Needs 96 x stride x 2 B of LDS per workgroup.
+//                  workgroup and feeds 6 MFMAs. Needs 96 x (stride + 32) x 2 B of LDS per workgroup.
 //   t6, t4       : 8 waves = 4 output-feature groups x 2 row groups of 96 / 64 rays (t4: any width up to 384).
 constexpr uint32_t kNifMaxLdsBytes = 160 * 1024 - 2048;   // dynamic LDS: what is left beside the static coordinate staging (2 x 192 floats)
 constexpr uint32_t kNifMaxLayers = 16;
