@@ -77,7 +77,6 @@ struct NifLayerDesc {
   uint32_t n;             // real output width
   uint32_t inBase;        // first LDS column of the layer's input
   uint32_t wOffset;       // offset (in h8 units) of the packed weights
-  uint32_t bOffset;       // offset (floats) of the bias, 0xFFFFFFFF = none
   uint32_t relu;
 };
 
@@ -91,7 +90,6 @@ struct NifParams {
 struct NifDevice {
   NifParams p{};
   h8* d_weights = nullptr;
-  float* d_bias = nullptr;
   uint32_t* d_count = nullptr;     // compaction counter
   uint32_t* d_index = nullptr;     // compacted ray indices
   size_t indexCap = 0;
@@ -100,10 +98,9 @@ struct NifDevice {
   bool loaded() const { return ok; }
   void release() {
     if (d_weights) (void)hipFree(d_weights);
-    if (d_bias) (void)hipFree(d_bias);
     if (d_count) (void)hipFree(d_count);
     if (d_index) (void)hipFree(d_index);
-    d_weights = nullptr; d_bias = nullptr; d_count = nullptr; d_index = nullptr; indexCap = 0; ok = false;
+    d_weights = nullptr; d_count = nullptr; d_index = nullptr; indexCap = 0; ok = false;
   }
 
   // Packs W (Keras [rows=K][cols=N], y = x·W) into A-fragment order of v_mfma_f32_16x16x32_f16 for the
@@ -125,7 +122,6 @@ struct NifDevice {
     P.stride = kPadMax;   // halves per ray (a multiple of 32); the image is k-chunk major (nif_x_byte)
     P.maxValue = maxValue; P.mean[0] = mean[0]; P.mean[1] = mean[1]; P.mean[2] = mean[2]; P.logTonemap = logTonemap;
     std::vector<_Float16> packed;
-    std::vector<float> bias;
     uint32_t width = F;
     bool inputIsFeatures = true;
     for (uint32_t l = 0; l < numLayers; ++l) {
@@ -166,17 +162,11 @@ struct NifDevice {
               packed.push_back((_Float16)w);
             }
       }
-      if (biases && biases[l]) { L.bOffset = (uint32_t)bias.size(); for (uint32_t n = 0; n < N; ++n) bias.push_back(biases[l][n]); for (uint32_t n = N; n < L.nTiles * 16; ++n) bias.push_back(0.f); }
-      else L.bOffset = 0xFFFFFFFFu;
       width = N;
       inputIsFeatures = false;
     }
     if (hipMalloc(&d_weights, packed.size() * sizeof(_Float16)) != hipSuccess) throw std::runtime_error("NIF: hipMalloc failed");
     (void)hipMemcpy(d_weights, packed.data(), packed.size() * sizeof(_Float16), hipMemcpyHostToDevice);
-    if (!bias.empty()) {
-      if (hipMalloc(&d_bias, bias.size() * sizeof(float)) != hipSuccess) throw std::runtime_error("NIF: hipMalloc failed");
-      (void)hipMemcpy(d_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice);
-    }
     if (hipMalloc(&d_count, sizeof(uint32_t)) != hipSuccess) throw std::runtime_error("NIF: hipMalloc failed");
     p = P;
     ok = true;
@@ -271,7 +261,7 @@ __global__ void __launch_bounds__(256) escaped_uv_kernel(const mi_trace_result* 
 template <uint32_t TN, uint32_t MT, uint32_t ROWS, bool LAST>
 __device__ __forceinline__ void nif_dense_layers(const NifParams& P, uint32_t l0, uint32_t l1, _Float16* X,
                                                  uint32_t rowBase, uint32_t ng, uint32_t lane, const h8* __restrict__ weights,
-                                                 const float* __restrict__ bias, uint32_t row0, uint32_t total,
+                                                 uint32_t row0, uint32_t total,
                                                  const uint32_t* __restrict__ idx, float* __restrict__ bgrOut, mi_trace_result* rays, bool scatter
 #if MI_NIF_STAMPS
                                                  , unsigned long long (&stampSum)[8]
@@ -495,7 +485,7 @@ __device__ __forceinline__ void nif_dense_layers(const NifParams& P, uint32_t l0
 // rays[idx[r]].rgb as throughput * (b,g,r)->(r,g,b) (PostProcessEscapedRays).
 // TILES = most output-feature tiles any layer gives a wave; layers with fewer run their own instantiation.
 template <uint32_t TILES, uint32_t MT, uint32_t RG>
-__global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : 1) nif_mlp_kernel(NifParams P, const h8* __restrict__ weights, const float* __restrict__ bias,
+__global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : 1) nif_mlp_kernel(NifParams P, const h8* __restrict__ weights,
                                                       const float* __restrict__ u, const float* __restrict__ v,
                                                       const uint32_t* __restrict__ idx, const uint32_t* __restrict__ countPtr,
                                                       uint32_t numRows, float* __restrict__ bgrOut, mi_trace_result* rays, bool scatter) {
@@ -577,8 +567,8 @@ __global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : 1) nif_ml
 #else
 #define MI_NIF_STAMP_ARG
 #endif
-#define MI_NIF_RUN(TN) do { if (finalLayer) nif_dense_layers<TN, MT, kNifRows, true>(P, l, l1, X, rowBase, ng, lane, weights, bias, row0, total, idx, bgrOut, rays, scatter MI_NIF_STAMP_ARG); \
-                            else nif_dense_layers<TN, MT, kNifRows, false>(P, l, l1, X, rowBase, ng, lane, weights, bias, row0, total, idx, bgrOut, rays, scatter MI_NIF_STAMP_ARG); } while (0)
+#define MI_NIF_RUN(TN) do { if (finalLayer) nif_dense_layers<TN, MT, kNifRows, true>(P, l, l1, X, rowBase, ng, lane, weights, row0, total, idx, bgrOut, rays, scatter MI_NIF_STAMP_ARG); \
+                            else nif_dense_layers<TN, MT, kNifRows, false>(P, l, l1, X, rowBase, ng, lane, weights, row0, total, idx, bgrOut, rays, scatter MI_NIF_STAMP_ARG); } while (0)
       if (tilesLayer == TILES) MI_NIF_RUN(TILES);
       if constexpr (TILES > 1) { if (tilesLayer == 1) MI_NIF_RUN(1); }
       if constexpr (TILES > 2) { if (tilesLayer == 2) MI_NIF_RUN(2); }
@@ -619,7 +609,7 @@ inline void nif_launch_mlp(const NifDevice& nif, const float* u, const float* v,
     uint32_t blocks = (numRows + rowsPerPass - 1) / rowsPerPass;
     if (blocks > 256 * 8) blocks = 256 * 8;          // grid-stride beyond 8 passes per CU
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNifMaxLdsBytes);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, nif.p, nif.d_weights, nif.d_bias, u, v, idx, countPtr, numRows, bgrOut, rays, scatter);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, nif.p, nif.d_weights, u, v, idx, countPtr, numRows, bgrOut, rays, scatter);
   };
   if (mt == 6 && rg == 1) {
     if (maxTiles <= 2) launch(nif_mlp_kernel<2, 6, 1>, 96, 256);
