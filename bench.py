@@ -8,11 +8,18 @@ length 10, roulette start depth 3, AA sigma 0.25 px, seed 1442).
 A "step" is one full frame: every pixel's 1000 samples, traced by ONE launch of the path-trace
 kernel over a ray stream that is already resident in HBM.
   N = 1   BASELINE config 2: 1440x1440 x 1000 spp.
-  N > 1   BASELINE config 4: 2880x2880 x 1000 spp, one process per GPU (torch.distributed.run), the frame's 8-row
-          bands dealt round-robin to the ranks (rays are the shard, the scene is replicated; the dealing is the C
-          code the single-process `trace --gpus N` path uses, mi_shard_* in libmi_scene_host.so), no exchange while
-          the frame renders, and ONE RCCL gather of the rgb tiles to rank 0 at frame end — inside the timed region.
+  N > 1   BASELINE config 4: 2880x2880 x 1000 spp, the frame's 8-row bands dealt round-robin to the GPUs (rays are the
+          shard, the scene is replicated), no exchange while the frame renders, and ONE RCCL gather at frame end -
+          inside the timed region. Two launch forms, the same dealing (csrc/ray_shard.hpp) behind both:
+            "launch": "ranks"  under torch.distributed.run (WORLD_SIZE = N): one process per GPU, rank 0 gathers the
+                               rgb tiles with one dist.gather;
+            "launch": "group"  started as a plain `python bench.py --gpus N` (WORLD_SIZE unset): ONE process drives
+                               the N devices through the C++ host path mi_group_* (what `trace --gpus N` runs): shares
+                               resident on their devices, timed region = K x mi_group_trace (trace + one RCCL
+                               send/recv group call of the full TraceResults to device 0).
           The frame is the same for N = 2, 4, 8 ("scaling": "strong"); --weak renders N x 1440^2 pixels instead.
+          For N > 1 the line also carries "one_gpu_same_frame_ms": the same frame on one device alone, measured in
+          the same run, as the anchor of the scaling curve.
 
 After the timed loop (outside it) rank 0 at N = 1
   * copies ~2 000 pixels of the LAST timed frame back and compares all 84 bytes of each with the CPU oracle run over
@@ -46,7 +53,7 @@ HBM_PEAK_GBS = 8000.0
 L2_PEAK_GBS = 34500.0
 L1_BYTES_PER_CLK_PER_CU = 64.0
 MFMA_F16_PEAK_TFLOPS = 2500.0
-PMC_SUMMARY = ROOT / "profiles" / "r02_pmc_summary.json"   # rocprofv3 --pmc passes of this same command (tools/prof_k1w.sh + tools/collect_profiles.py)
+PMC_SUMMARY = ROOT / "profiles" / "r02_pmc_summary.json"   # rocprofv3 --pmc passes of this same command (tools/prof_r02.sh + tools/collect_profiles.py)
 
 
 def image_shape(n_gpus: int, base: int, weak: bool):
@@ -100,6 +107,96 @@ def nif_weights(rng, hidden=320, embed=12, layers=6):
     return ks, bs, [1] * (len(dims) - 1) + [0], dims
 
 
+def one_gpu_same_frame_ms(torch, irl, desc, width, height, device):
+    """The N > 1 frame on ONE GPU (device `device`), device-resident stream, one warm-up + two timed launches: the
+    same-frame anchor of the scaling curve, measured in the same run."""
+    d1 = irl.SceneDesc.from_buffer_copy(desc)
+    d1.device = device
+    torch.cuda.set_device(device)
+    dev = irl.IpuScene(d1)
+    rows, cols = np.divmod(np.arange(width * height, dtype=np.int64), width)
+    rays = to_device(torch, irl, make_stream(irl, rows, cols))
+    st = torch.cuda.current_stream()
+    ms = time_launches(torch, lambda: dev.run_device(rays.data_ptr(), width * height, irl.MODE_PATH_TRACE, st.cuda_stream), 2, st)
+    dev.close()
+    return ms
+
+
+def bench_group(args, torch, irl):
+    """--gpus N > 1 in ONE process: the C++ host path (mi_group_*, csrc/group_render.hpp). One scene replica per device
+    0..N-1, the frame dealt in 8-row bands, shares resident on their devices; a step = mi_group_trace = every replica
+    traces its share + ONE RCCL group call gathers the shares on device 0."""
+    n_gpus = args.gpus
+    width, height = image_shape(n_gpus, args.size, args.weak)
+    scene = irl.HostScene.builtin(args.scene)
+    d = scene.desc
+    d.set_image(width, height)
+    d.samples_per_pixel = args.spp
+    d.path_trace = 1
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(n_gpus))
+    if len(devices) != n_gpus:
+        raise SystemExit(f"bench.py: --devices names {len(devices)} replicas, --gpus {n_gpus}")
+    try:
+        grp = irl.IpuGroup(d, devices, irl.TRANSPORT_RCCL)
+    except irl.RaylibError as e:
+        raise SystemExit(f"bench.py --gpus {n_gpus} (single-process group path, {torch.cuda.device_count()} GPU(s) visible): {e}")
+    n = width * height
+    host_rays = scene.init_ray_stream()
+    grp.upload(host_rays)
+    for _ in range(args.warmup):
+        grp.trace(irl.MODE_PATH_TRACE)
+    grp.reset_counters()
+    for dev_i in sorted(set(devices)):
+        torch.cuda.synchronize(dev_i)
+    step_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        grp.trace(irl.MODE_PATH_TRACE)            # returns when every replica's stream and the gather have drained
+        step_ms.append(grp.getTraceTimeSecs() * 1e3)
+    for dev_i in sorted(set(devices)):
+        torch.cuda.synchronize(dev_i)
+    elapsed = time.perf_counter() - t0
+    c = grp.counters()
+    moved = grp.last_transfer()
+    out = {
+        "metric": "rays/sec (ray casts/s: CompactBvh intersect+occluded calls, whole node), built-in scene 1440x1440 path-trace",
+        "value": c["casts"] / elapsed, "unit": "rays/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
+        "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (built-in Cornell box + monkey bust scene, seeded per-pixel RNG streams)",
+        "config": {"workload": f"built-in scene '{args.scene}', path-trace {width}x{height} x {args.spp} spp, max path length 10, "
+                               f"roulette depth 3, AA 0.25, seed 1442 (BASELINE config {'4' if not args.weak else '2, weak-scaled frame'})",
+                   "parallelism": f"ray bands x{n_gpus}, one process (mi_group_*) on devices {devices}, 1 RCCL send/recv group call per frame"},
+        "paths_per_s": c["paths"] / elapsed, "ms_per_frame": elapsed / max(args.steps, 1) * 1e3,
+        "casts_per_path": c["casts"] / max(c["paths"], 1), "launch": "group",
+        "step_ms": step_ms, "gather": {"rccl_messages": moved["rccl_messages"], "peer_copies": moved["peer_copies"],
+                                        "bytes_to_root": int((n - grp.gathered_device()[1][1]) * irl.TRACE_RESULT.itemsize)},
+    }
+    rc = 0
+    if not args.no_cpu_baseline:
+        import oracle_lib
+        cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+        got = grp.download(host_rays.copy())
+        frames = args.warmup + args.steps
+        stride = max(1, n // 1009)
+        want = scene.init_ray_stream()[::stride].copy()
+        tp = time.perf_counter()
+        for _ in range(frames):
+            oracle_lib.path_trace_pixel_rng(d, want, cores)
+        gb = got[::stride].copy().view(np.uint8).reshape(want.size, -1); wb = want.view(np.uint8).reshape(want.size, -1)
+        bad = int((gb != wb).any(axis=1).sum())
+        out["parity_checked_pixels"] = int(want.size); out["parity_mismatches"] = bad
+        out["parity_note"] = (f"every {stride}th pixel of the gathered frame after {frames} accumulated frames, all 84 bytes, vs "
+                              f"oracle/ray_oracle.c ({time.perf_counter() - tp:.1f} s)")
+        rc = 1 if bad else 0
+    grp.close()
+    out["one_gpu_same_frame_ms"] = one_gpu_same_frame_ms(torch, irl, d, width, height, 0)
+    out["roofline"] = {"kernel": "path_trace_wavefront_kernel", "note": "see the N = 1 line: the per-GPU kernel is the same launch on a share of the frame"}
+    print(json.dumps(out), flush=True)
+    if rc:
+        sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,6 +206,8 @@ def main():
     ap.add_argument("--spp", type=int, default=1000, help="samples per pixel (default = BASELINE config)")
     ap.add_argument("--scene", default="box")
     ap.add_argument("--weak", action="store_true", help="N>1: N x size^2 pixels instead of config 4's fixed (2 size)^2 frame")
+    ap.add_argument("--devices", default="", help="N>1, single-process group path: comma list of HIP ordinals, one per replica (default 0..N-1; "
+                                                  "ordinals may repeat - '0,0' rehearses the two-GPU path on a one-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (parity spot check and CPU baseline)")
     ap.add_argument("--no-extras", action="store_true", help="skip the instrumented probe, the NIF kernel and the 16-spp frame (profiling runs)")
     args = ap.parse_args()
@@ -119,11 +218,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    # Native libraries travel prebuilt; the build steps are no-ops when a binary's recorded source hash matches the
+    # sources beside it. Only ONE process per node rebuilds what is missing or stale, and it does so before anything
+    # touches the GPU or joins the process group (the rendezvous only happens afterwards, so no rank sits in a
+    # collective while hipcc runs).
+    import __graft_entry__ as ge
+    if local_rank == 0:
+        ge.build_cpu()
+        ge.build_device()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if world == 1 and args.gpus > 1:
+        return bench_group(args, torch, irl)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it either as a plain process (single-process "
+                         f"group path) or under torch.distributed.run with --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -131,14 +240,6 @@ def main():
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    # Native libraries travel prebuilt; the build steps are no-ops when the binaries are newer than their sources,
-    # and only ONE process per node rebuilds what is missing or stale
-    import __graft_entry__ as ge
-    if local_rank == 0:
-        ge.build_cpu()
-        ge.build_device()
-    if dist is not None:
         dist.barrier()
 
     width, height = image_shape(world, args.size, args.weak)
@@ -231,7 +332,10 @@ def main():
         "paths_per_s": total_paths / elapsed,
         "ms_per_frame": elapsed / max(args.steps, 1) * 1e3,
         "casts_per_path": total_casts / max(total_paths, 1.0),
+        "launch": "ranks" if world > 1 else "single",
     }
+    if world > 1:
+        out["one_gpu_same_frame_ms"] = one_gpu_same_frame_ms(torch, irl, d, width, height, local_rank)
 
     # ---------------- roofline of the dominant kernel (the path-trace launch) ----------------
     # Algorithmic bytes per cast: 24 B per node visited + the 42-B primitive record per leaf test + one

@@ -204,11 +204,21 @@ int mi_scene_set_ray_batch(mi_scene* scene, size_t rays_per_batch);
 
 /* Kernel selection / tuning of ONE scene (no reference counterpart; the nearest is the reference's per-run
  * RuntimeConfig + codelet build flags, trace.cpp:297-309). Every scene carries its own copy: defaults, overridden
- * by the MI_RAYLIB_* environment variables as they stand when the scene is created, then by this call. Keys:
- * "kernel" 0|1|2 (nested-loop / phase-scheduled / phase-scheduled + LDS-staged nodes), "waves" 4|5, "full_stats" 0|1
- * (instrumented kernels: node / leaf-test counters and phase occupancy), "tune" "leafAt,shadeAt,genAt[,...]",
- * "tiles" 0|1, "seg_budget_kb" N, "nif_spl" N (NIF samples per launch), "nif_shape" w6|t6|t4, "pin" 0|1.
- * None of them changes a result bit. Returns MI_ERR_INVALID_ARG for an unknown key or unparsable value. */
+ * by the MI_RAYLIB_* environment variables as they stand when the scene is created, then by this call. Keys and the
+ * values each accepts (anything else: MI_ERR_INVALID_ARG, the option keeps its value):
+ *   "kernel"        0 | 1 | 2 | 3   nested-loop / phase-scheduled (default) / phase-scheduled + LDS-staged nodes / path pool
+ *   "waves"         4 | 5           waves per SIMD the default kernel is built for (5: the 96-VGPR build)
+ *   "spec"          0 | 1           kernel 1: lanes walk on past ONE pending primitive test
+ *   "full_stats"    0 | 1           instrumented kernels: node / leaf-test counters, phase occupancy
+ *   "tune"          "leafAt,shadeAt,genAt[,burst,keep8,dbl,maxExtra(<=5),leafThenNode,prio,leafP]"   scheduling weights of kernel 1
+ *   "pool_waves"    4 | 8 | 16      kernel 3: waves per workgroup
+ *   "pool_tune"     "leafAt,burst,retireAt,refillMin,shadeW,genW[,dbl,maxExtra,leafThenNode,prio]"
+ *   "tiles"         0 | 1           walk row-structured streams in 8x8 pixel tiles
+ *   "seg_budget_kb" N >= 1          partial-sum buffer budget per launch
+ *   "nif_spl"       0..128          NIF samples per launch (0 = default)
+ *   "nif_shape"     w6 | t6 | t4    workgroup shape of the NIF MLP kernel
+ *   "pin"           0 | 1           page-lock the caller's stream for the duration of mi_render
+ * None of them changes a result bit. The keys "fast" and "double_fallback" (below) select arithmetic variants and DO. */
 int mi_scene_set_option(mi_scene* scene, const char* key, const char* value);
 
 /* The NIF environment evaluated stand-alone on device arrays: for i<n, bgr[i*3..] =
@@ -220,19 +230,21 @@ int mi_nif_infer_device(mi_scene* scene, const float* d_u, const float* d_v, flo
 /* ---- several GPUs in one process -------------------------------------------------------
  * Replaces: the replicas of an IpuScene (RuntimeConfig.numIpus / numReplicas, trace.cpp:297-309; scene replicated per
  * device src/IpuScene.cpp:473-483; replicas pull disjoint ray batches round-robin from the one stream :676-684; every
- * batch is written back into the caller's stream :699-732).
+ * batch is written back into the caller's stream :699-732 and handed to the callback, src/RayCallback.cpp:8-24).
  * mi_group_create builds one mi_scene per entry of `devices` (HIP ordinals; an ordinal may repeat - several replicas
- * then share that GPU, which is how the path is rehearsed on a one-GPU box). mi_group_render deals the host stream in
- * bands (8 rows of the render window per band, band b to replica b % R: ipu_ray_lib_amd/csrc/ray_shard.hpp, also
- * exported as mi_shard_* by libmi_scene_host.so), traces every replica's share on its own HIP stream with no exchange
- * while the frame renders, moves the finished shares to the first replica's device with ONE RCCL group call
- * (ncclSend / ncclRecv over xGMI), restores stream order there and overwrites `rays` in place. Every pixel owns its
- * RNG streams, so the result is bit-identical for any number of replicas.
+ * then share that GPU, which is how the path is rehearsed on a one-GPU box). mi_group_render cuts the host stream into
+ * ray batches (mi_group_set_ray_batch; default: one batch = the whole stream) and, for each batch: deals it in bands
+ * (8 rows of the render window per band, band b to replica b % R: ipu_ray_lib_amd/csrc/ray_shard.hpp, also exported as
+ * mi_shard_* by libmi_scene_host.so), uploads every replica's bands with one strided copy, traces every share on its
+ * own HIP stream with no exchange while it renders, moves the finished shares to the first replica's device with ONE
+ * RCCL group call (ncclSend / ncclRecv over xGMI), and copies them from there straight into their places in `rays`
+ * (strided copies: no de-interleave pass, no second frame buffer). The callback is called once per batch, in batch
+ * order, on the calling thread, as soon as that batch is home and while the next one is being traced. Every pixel owns
+ * its RNG streams, so the result is bit-identical for any number of replicas and any batch size.
  * `transport`: 0 = RCCL as soon as more than one device takes part (peer copies otherwise), 1 = RCCL always, 2 = peer
  * copies only. RCCL is loaded with dlopen when the first group needs it.
  * mi_group_scene hands out a replica's scene for the per-scene setters (mi_scene_set_nif, mi_scene_set_option, ...),
- * which must be applied to every replica alike. The callback is called once per ray batch, in batch order, after the
- * frame has been assembled. */
+ * which must be applied to every replica alike. */
 typedef struct mi_group mi_group;
 int mi_group_create(const mi_scene_desc* desc, const int32_t* devices, uint32_t num_replicas, int32_t transport, mi_group** out);
 void mi_group_destroy(mi_group* group);
@@ -240,10 +252,23 @@ uint32_t mi_group_size(const mi_group* group);
 mi_scene* mi_group_scene(mi_group* group, uint32_t replica);
 int mi_group_set_ray_batch(mi_group* group, size_t rays_per_batch);
 int mi_group_render(mi_group* group, int mode, mi_trace_result* rays, size_t n, mi_ray_callback cb, void* user);
-double mi_group_trace_time_secs(const mi_group* group);
+/* The stages of mi_group_render one by one, for callers that keep the shares RESIDENT on the devices (the reference
+ * keeps a batch in remote buffers between executions the same way, src/IpuScene.cpp:399-409): upload deals and copies
+ * the whole stream (one batch); trace renders every share where it lies and gathers the shares on the first replica's
+ * device (rgb keeps accumulating from call to call, as with mi_render_device); download copies the gathered shares into
+ * `rays` (n must be the uploaded count). bench.py --gpus N times mi_group_trace: inputs resident in HBM, the RCCL
+ * gather inside the timed region. mi_group_gathered_device exposes the gathered buffer (shares replica after replica;
+ * offsets[r] = first record of replica r's share, up to num_offsets entries) for device-side consumers. */
+int mi_group_upload(mi_group* group, const mi_trace_result* rays, size_t n);
+int mi_group_trace(mi_group* group, int mode);
+int mi_group_download(mi_group* group, mi_trace_result* rays, size_t n);
+int mi_group_gathered_device(mi_group* group, void** d_gathered, uint64_t* offsets, uint32_t num_offsets);
+double mi_group_trace_time_secs(const mi_group* group);               /* wall time of the last mi_group_render / mi_group_trace */
 int mi_group_get_counters(mi_group* group, uint64_t counts[4]);       /* summed over the replicas */
-/* What the last mi_group_render moved: info[0] = RCCL send/recv pairs, info[1] = peer copies, info[2] = bands uploaded. */
-int mi_group_last_transfer(const mi_group* group, uint64_t info[3]);
+int mi_group_reset_counters(mi_group* group);
+/* What the last mi_group_render (or stage call) moved: info[0] = RCCL send/recv pairs, info[1] = peer copies,
+ * info[2] = bands dealt, info[3] = host->device copies issued, info[4] = device->host copies issued. */
+int mi_group_last_transfer(const mi_group* group, uint64_t info[5]);
 
 /* Thread-local message for the last failing call on this thread. Never NULL. */
 const char* mi_last_error(void);

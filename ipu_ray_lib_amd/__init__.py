@@ -193,6 +193,11 @@ def device_lib() -> C.CDLL:
         lib.mi_group_trace_time_secs.restype = C.c_double
         lib.mi_group_get_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         lib.mi_group_last_transfer.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        lib.mi_group_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.mi_group_trace.argtypes = [C.c_void_p, C.c_int]
+        lib.mi_group_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.mi_group_gathered_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_uint32]
+        lib.mi_group_reset_counters.argtypes = [C.c_void_p]
         lib.mi_get_pool_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         lib.mi_scene_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         _device = lib
@@ -529,9 +534,33 @@ class IpuGroup:
         return {"casts": c[0], "nodes_visited": c[1], "leaf_tests": c[2], "paths": c[3]}
 
     def last_transfer(self) -> dict:
-        c = (C.c_uint64 * 3)()
+        c = (C.c_uint64 * 5)()
         _check_dev(self._lib.mi_group_last_transfer(self._h, c))
-        return {"rccl_messages": c[0], "peer_copies": c[1], "bands": c[2]}
+        return {"rccl_messages": c[0], "peer_copies": c[1], "bands": c[2], "upload_copies": c[3], "download_copies": c[4]}
+
+    # -- the stages one by one: the shares stay resident on the devices between calls --
+    def upload(self, rays: np.ndarray):
+        assert rays.dtype == TRACE_RESULT and rays.flags["C_CONTIGUOUS"]
+        _check_dev(self._lib.mi_group_upload(self._h, rays.ctypes.data, rays.size))
+
+    def trace(self, mode: int = MODE_PATH_TRACE):
+        _check_dev(self._lib.mi_group_trace(self._h, mode))
+
+    def download(self, rays: np.ndarray) -> np.ndarray:
+        assert rays.dtype == TRACE_RESULT and rays.flags["C_CONTIGUOUS"]
+        _check_dev(self._lib.mi_group_download(self._h, rays.ctypes.data, rays.size))
+        return rays
+
+    def gathered_device(self):
+        """(device pointer of the gathered shares on the first replica's device, first record of every replica's share)"""
+        ptr = C.c_void_p()
+        n = self._lib.mi_group_size(self._h)
+        off = (C.c_uint64 * (n + 1))()
+        _check_dev(self._lib.mi_group_gathered_device(self._h, C.byref(ptr), off, n + 1))
+        return ptr.value, [int(x) for x in off]
+
+    def reset_counters(self):
+        _check_dev(self._lib.mi_group_reset_counters(self._h))
 
     def close(self):
         if self._h:

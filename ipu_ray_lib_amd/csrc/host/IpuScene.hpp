@@ -108,7 +108,7 @@ class IpuScene {
     return c[0];
   }
   // RCCL send/recv pairs, peer copies and bands of the last multi-replica render (zeros for a single scene)
-  void lastTransfer(uint64_t info[3]) const { info[0] = info[1] = info[2] = 0; if (group) mi_group_last_transfer(group, info); }
+  void lastTransfer(uint64_t info[5]) const { for (int i = 0; i < 5; ++i) info[i] = 0; if (group) mi_group_last_transfer(group, info); }
 
  private:
   static void trampoline(void* user, size_t batch, const mi_trace_result* rays, size_t count) {

@@ -267,10 +267,10 @@ int main(int argc, char** argv) {
   logf(2, "info", "GPU %s per second: %g", sceneRef.path_trace ? "paths" : "rays", rayStream.size() * castsPerRay / secs);
   logf(2, "info", "GPU ray casts per second: %g", (double)gpuScene.rayCasts() / secs);
   {
-    uint64_t moved[3];
+    uint64_t moved[5];
     gpuScene.lastTransfer(moved);
-    if (moved[2]) logf(2, "info", "Replicas: %u on %u GPU(s); %llu bands dealt, gathered with %llu RCCL send/recv pairs and %llu peer copies", rc.numReplicas, rc.numGpus,
-                       (unsigned long long)moved[2], (unsigned long long)moved[0], (unsigned long long)moved[1]);
+    if (moved[2]) logf(2, "info", "Replicas: %u on %u GPU(s); %llu bands dealt in %llu strided uploads, gathered with %llu RCCL send/recv pairs and %llu peer copies", rc.numReplicas, rc.numGpus,
+                       (unsigned long long)moved[2], (unsigned long long)moved[3], (unsigned long long)moved[0], (unsigned long long)moved[1]);
   }
 
   std::vector<float> image;

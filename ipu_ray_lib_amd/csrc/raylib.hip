@@ -90,35 +90,59 @@ struct SceneOptions {
   bool pin = true;                 // MI_RAYLIB_PIN / "pin": page-lock the caller's stream for the duration of mi_render
   uint32_t nifShape = 0;           // MI_RAYLIB_NIF_SHAPE / "nif_shape": 0 = w6 (default), 1 = t6, 2 = t4
 
+  // Every key takes values from a stated domain; anything else leaves the option as it was and returns false
+  // (mi_scene_set_option then reports MI_ERR_INVALID_ARG, as include/mi_raylib.h promises).
+  static bool flag01(const char* v, bool& out) {
+    if ((v[0] != '0' && v[0] != '1') || v[1] != '\0') return false;
+    out = v[0] == '1';
+    return true;
+  }
+  static bool number(const char* v, unsigned long long lo, unsigned long long hi, unsigned long long& out) {
+    if (!*v) return false;
+    char* end = nullptr;
+    const unsigned long long q = strtoull(v, &end, 10);
+    if (!end || *end != '\0' || v[0] == '-' || q < lo || q > hi) return false;
+    out = q;
+    return true;
+  }
   bool set(const std::string& key, const char* v) {
     if (!v) return false;
-    if (key == "full_stats") fullStats = v[0] == '1';
-    else if (key == "kernel") kernelChoice = (v[0] == '0') ? 0 : (v[0] == '2') ? 2 : (v[0] == '3') ? 3 : 1;
-    else if (key == "pool_waves") { const int q = atoi(v); if (q != 4 && q != 8 && q != 16) return false; poolWaves = q; }
-    else if (key == "pool_tune") {
+    unsigned long long q = 0;
+    if (key == "full_stats") return flag01(v, fullStats);
+    if (key == "kernel") { if (!number(v, 0, 3, q)) return false; kernelChoice = (int)q; return true; }
+    if (key == "pool_waves") { if (!number(v, 4, 16, q) || (q != 4 && q != 8 && q != 16)) return false; poolWaves = (int)q; return true; }
+    if (key == "pool_tune") {
       unsigned a, b, c, d, e, f, db = 4, mx = 5, ln = 1, pr = 1;
       if (sscanf(v, "%u,%u,%u,%u,%u,%u,%u,%u,%u,%u", &a, &b, &c, &d, &e, &f, &db, &mx, &ln, &pr) < 6) return false;
       poolTune = {a, b, c ? c : 1, d ? d : 1, e, f, db ? db : 65, mx, ln, pr};
+      return true;
     }
-    else if (key == "waves") wavesPerSimd = (v[0] == '4') ? 4 : 5;
-    else if (key == "spec") specLeaf = v[0] == '1';
-    else if (key == "tiles") tiles = v[0] != '0';
-    else if (key == "seg_budget_kb") segBudgetKb = std::max<size_t>((size_t)strtoull(v, nullptr, 10), 1);
-    else if (key == "nif_spl") nifSamplesPerLaunch = (uint32_t)atoi(v);
-    else if (key == "pin") pin = v[0] != '0';
-    else if (key == "nif_shape") nifShape = (v[0] == 't') ? ((v[1] == '6') ? 1u : 2u) : 0u;
-    else if (key == "tune") {      // leafAt,shadeAt,genAt[,burst,keep8,dbl,maxExtra,leafThenNode,prio]
+    if (key == "waves") { if (!number(v, 4, 5, q)) return false; wavesPerSimd = (int)q; return true; }
+    if (key == "spec") return flag01(v, specLeaf);
+    if (key == "tiles") return flag01(v, tiles);
+    if (key == "seg_budget_kb") { if (!number(v, 1, ~0ull >> 12, q)) return false; segBudgetKb = (size_t)q; return true; }
+    if (key == "nif_spl") { if (!number(v, 0, 128, q)) return false; nifSamplesPerLaunch = (uint32_t)q; return true; }
+    if (key == "pin") return flag01(v, pin);
+    if (key == "nif_shape") {
+      const std::string s(v);
+      if (s == "w6") nifShape = 0; else if (s == "t6") nifShape = 1; else if (s == "t4") nifShape = 2; else return false;
+      return true;
+    }
+    if (key == "tune") {      // leafAt,shadeAt,genAt[,burst,keep8,dbl,maxExtra,leafThenNode,prio,leafP]
       unsigned a, b, c, dd = 48, k8 = 3, db = 4, mx = 5, ln = 1, pr = 1, lp = 40;
       if (sscanf(v, "%u,%u,%u,%u,%u,%u,%u,%u,%u,%u", &a, &b, &c, &dd, &k8, &db, &mx, &ln, &pr, &lp) < 3) return false;
+      if (mx > 5) return false;          // the spelled-out run of box tests has six
       tune = {a, b, c, dd, k8, db ? db : 65, mx, ln, pr, lp ? lp : 1};
-    } else return false;
-    return true;
+      return true;
+    }
+    return false;
   }
   void fromEnvironment() {
     static const char* const map[][2] = {{"MI_RAYLIB_FULL_STATS", "full_stats"}, {"MI_RAYLIB_KERNEL", "kernel"}, {"MI_RAYLIB_WAVES", "waves"}, {"MI_RAYLIB_SPEC", "spec"},
                                          {"MI_RAYLIB_SEG_BUDGET_KB", "seg_budget_kb"}, {"MI_RAYLIB_NIF_SPL", "nif_spl"}, {"MI_RAYLIB_PIN", "pin"},
                                          {"MI_RAYLIB_NIF_SHAPE", "nif_shape"}, {"MI_RAYLIB_TUNE", "tune"},
                                          {"MI_RAYLIB_POOL_TUNE", "pool_tune"}, {"MI_RAYLIB_POOL_WAVES", "pool_waves"}};
+    // (an unparsable environment value is ignored: the option keeps its default)
     for (const auto& m : map) if (const char* e = getenv(m[0])) (void)set(m[1], e);
     if (getenv("MI_RAYLIB_NO_TILES")) tiles = false;
   }
@@ -387,7 +411,7 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
   // 8-row bands are all sequences of full rows); the walk is only a work ORDER, any stream stays correct.
   const uint32_t w = (uint32_t)S.params.window_w;
   const uint32_t tileW = (S.opt.tiles && w >= 8 && (w % 8) == 0 && cnt >= 8u * w) ? w : 0u;
-  const bool plain = ex.slotColor == nullptr;      // NIF launches (slots) only exist for the default kernel
+  const bool plain = ex.slotColor == nullptr;      // NIF launches leave slots instead of partial sums (kernels 1 and 3 take them; kernel 2 falls through to kernel 1)
   // Pixels with more than segment_samples(spp) samples are traced as (pixel, segment) work atoms (ray_math.h); every
   // stream has its own partial-sum buffer (LaunchSlot).
   const uint32_t segLen = segment_samples(S.ds.samplesPerPixel);

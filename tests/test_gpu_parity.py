@@ -794,6 +794,36 @@ def test_config5_monkey_nif_1440_x_256spp_against_oracle():
     dev.close()
 
 
+def test_config5_monkey_nif_1440_x_4000spp_against_oracle():
+    """BASELINE config 5 at its real size on one GPU: monkey bust + NIF environment, 1440x1440 x 4000 spp (63 segments
+    per pixel, 32 launches of 128 samples' slots). Every 6421st pixel (323 pixels) against the oracle's NIF render at
+    4000 spp: hit records bit exact; rgb sums within the MLP tolerance of test_nif_mlp_against_oracle (2 % relative on a
+    decoded radiance; a pixel's sum averages 4000 samples: 1 % + a small absolute term for 99 % of the pixels, 5 %
+    for all)."""
+    rng = np.random.default_rng(8)
+    ks, bs, relu = _nif_weights(rng)
+    mean = np.array([-2.3514461517333984, -2.2660605907440186, -1.9648972749710083], np.float32) - np.float32(1e-8)
+    s = irl.HostScene.builtin("monkey"); d = s.desc
+    d.set_image(1440, 1440); d.samples_per_pixel = 4000; d.path_trace = 1
+    dev = irl.IpuScene(d)
+    dev.setNif(ks, bs, relu, 12, 3.4299468994140625, mean, True)
+    got = s.init_ray_stream()
+    dev.run(got, irl.MODE_PATH_TRACE)
+    want = s.init_ray_stream()[::6421].copy()
+    assert want.size >= 300
+    nif, keep = ol.make_nif(ks, bs, relu, 12, 3.4299468994140625, mean, True, half_features=True, half_weights_acts=True)
+    st = ol.Stats()
+    ol.lib().o_path_trace_nif_pixel_rng(C.byref(d), C.byref(nif), 0.0, want.ctypes.data, want.size, 16, C.byref(st))
+    sub = got[::6421].copy()
+    assert rows_differing(np.ascontiguousarray(sub["h"]), np.ascontiguousarray(want["h"])).size == 0, "config 5: hit records must be bit exact"
+    g = np.stack([sub["rgb"][k] for k in "xyz"], 1); w = np.stack([want["rgb"][k] for k in "xyz"], 1)
+    assert w.max() > 0
+    err = np.abs(g - w) / (np.abs(w) + 0.05 * 4000)
+    assert np.quantile(err, 0.99) < 0.01 and err.max() < 0.05, (np.quantile(err, 0.99), err.max())
+    assert dev.counters()["paths"] == 1440 * 1440 * 4000
+    dev.close()
+
+
 def test_gpu_image_against_the_literal_renderCPU_statistically(scenes):
     """Tier 2 on the GPU: the image the HIP path renders (per-pixel streams) against the oracle's literal restatement
     of renderCPU (trace.cpp:190-268: ONE shared generator consumed sequentially, libstdc++ normal_distribution
@@ -893,27 +923,60 @@ def test_one_scene_on_two_streams_concurrently(scenes):
 # ------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("replicas,transport", [(2, "rccl"), (3, "rccl"), (3, "copy"), (1, "auto")])
 def test_replica_group_renders_the_single_scene_frame(scenes, replicas, transport):
-    """The C++ multi-GPU path on ONE device: R replicas of the scene share GPU 0, the stream is dealt to them in
-    8-row bands, every share is traced on its own stream, and the shares reach the root replica through RCCL
-    (ncclSend / ncclRecv inside one group call; on one device the peers are the root's own rank) or through peer
-    copies; the de-interleaved frame must equal the single-scene render and the oracle, byte for byte - path trace
-    (ragged last band: 100 rows) and shadow trace, with the partial-result callback."""
+    """The C++ multi-GPU path on ONE device: R replicas of the scene share GPU 0, every ray batch is dealt to them in
+    8-row bands (one strided upload per replica), every share is traced on its own stream, and the shares reach the
+    root replica through RCCL (ncclSend / ncclRecv inside one group call per batch; on one device the peers are the
+    root's own rank) or through peer copies, and go home with one strided copy per replica; the frame must equal the
+    single-scene render and the oracle, byte for byte - path trace (ragged last band: 100 rows) and shadow trace.
+    The partial-result callback (RayCallback::fetch, src/RayCallback.cpp:8-24) is called per batch, in order, WHILE
+    the render runs: at callback b the batch is complete in the caller's stream and batch b + 2 has not been touched."""
     s = scenes["box"]; d = s.desc
     d.set_image(136, 100); d.samples_per_pixel = 9; d.path_trace = 1
     want = s.init_ray_stream(); st = ol.path_trace_pixel_rng(d, want, 16)
     code = {"auto": irl.TRANSPORT_AUTO, "rccl": irl.TRANSPORT_RCCL, "copy": irl.TRANSPORT_COPY}[transport]
     grp = irl.IpuGroup(d, [0] * replicas, code)
     got = s.init_ray_stream()
-    seen = []
-    grp.setRayBatch(5000)
-    grp.run(got, irl.MODE_PATH_TRACE, callback=lambda idx, first, cnt: seen.append((idx, first, cnt)))
+    fresh = got.copy()
+    seen, problems = [], []
+    batch = 5000
+    nb = (got.size + batch - 1) // batch
+
+    def on_batch(idx, first, cnt):
+        seen.append((idx, first, cnt))
+        if got[first:first + cnt].tobytes() != want[first:first + cnt].tobytes():
+            problems.append(f"batch {idx} is not complete at its callback")
+        if idx + 2 < nb:
+            lo = (idx + 2) * batch
+            if got[lo:lo + batch].tobytes() != fresh[lo:lo + batch].tobytes():
+                problems.append(f"batch {idx + 2} was already written at the callback of batch {idx}")
+
+    grp.setRayBatch(batch)
+    grp.run(got, irl.MODE_PATH_TRACE, callback=on_batch)
+    assert not problems, problems
     assert_streams_identical(got, want, f"{replicas} replicas, {transport}")
     assert grp.counters()["casts"] == st.casts and grp.counters()["paths"] == got.size * 9
-    assert seen == [(b, b * 5000, min(5000, got.size - b * 5000)) for b in range((got.size + 4999) // 5000)]
+    assert seen == [(b, b * batch, min(batch, got.size - b * batch)) for b in range(nb)]
     moved = grp.last_transfer()
-    assert moved["bands"] == 13                                     # 100 rows = 12 bands of 8 + one of 4
+    # 13 600 rays in batches of 5 000: unstructured batches are dealt in bands of 4 096 rays -> 2 + 2 + 1 bands
+    assert moved["bands"] == 5
+    if replicas > 1:      # one message per batch that has a second band (the third replica never gets one)
+        assert (moved["rccl_messages"], moved["peer_copies"]) == ((2, 0) if transport == "rccl" else (0, 2))
+    # the whole stream as one batch: 100 rows = 12 bands of 8 + one of 4, one strided copy per replica each way (+ the tail)
+    grp.setRayBatch(0)
+    g1 = s.init_ray_stream(); grp.run(g1, irl.MODE_PATH_TRACE)
+    assert_streams_identical(g1, want, f"{replicas} replicas, {transport}, one batch")
+    moved = grp.last_transfer()
+    assert moved["bands"] == 13
+    assert moved["upload_copies"] == min(replicas, 13) + 1 and moved["download_copies"] == moved["upload_copies"]
     if replicas > 1:
         assert (moved["rccl_messages"], moved["peer_copies"]) == ((replicas - 1, 0) if transport == "rccl" else (0, replicas - 1))
+    # the stages one by one with the shares resident: two frames accumulate like two oracle passes
+    twice = want.copy(); ol.path_trace_pixel_rng(d, twice, 16)
+    g3 = s.init_ray_stream()
+    grp.upload(g3); grp.trace(irl.MODE_PATH_TRACE); grp.trace(irl.MODE_PATH_TRACE); grp.download(g3)
+    assert_streams_identical(g3, twice, f"{replicas} replicas, {transport}, resident shares, two frames")
+    with pytest.raises(irl.RaylibError, match="differs from the resident"):
+        grp.download(g3[:100].copy())
     # shadow trace through the same group, twice (buffers and communicators are reused)
     d.path_trace = 0
     for _ in range(2):
@@ -922,6 +985,29 @@ def test_replica_group_renders_the_single_scene_frame(scenes, replicas, transpor
         assert_streams_identical(g2, w2, f"shadow trace, {replicas} replicas, {transport}")
     grp.close()
     d.path_trace = 1; d.set_image(96, 64); d.samples_per_pixel = 5
+
+
+def test_config4_frame_2880_x_1000spp_through_eight_replicas_and_rccl(scenes):
+    """BASELINE config 4 at its real size, as far as one GPU allows: the 2880x2880 x 1000 spp box frame through
+    mi_group_* with EIGHT replicas (all on device 0), RCCL transport - 360 bands of 8 rows dealt round-robin, one
+    strided upload per replica, ONE group call of 7 ncclSend / ncclRecv pairs, one strided download per replica.
+    Every 4001st pixel (2 074 pixels, all 84 bytes) against the oracle at the full 1000 spp."""
+    s = scenes["box"]; d = s.desc
+    d.set_image(2880, 2880); d.samples_per_pixel = 1000; d.path_trace = 1
+    grp = irl.IpuGroup(d, [0] * 8, irl.TRANSPORT_RCCL)
+    got = s.init_ray_stream()
+    grp.run(got, irl.MODE_PATH_TRACE)
+    moved = grp.last_transfer()
+    assert (moved["rccl_messages"], moved["peer_copies"], moved["bands"]) == (7, 0, 360)
+    assert moved["upload_copies"] == 8 and moved["download_copies"] == 8
+    sub = s.init_ray_stream()[::4001].copy()
+    st = ol.path_trace_pixel_rng(d, sub, 16)
+    assert_streams_identical(got[::4001].copy(), sub, "config 4: 2880^2 x 1000 spp, 8 replicas + RCCL, 1-in-4001 subsample")
+    c = grp.counters()
+    assert c["paths"] == 2880 * 2880 * 1000
+    assert abs(c["casts"] / c["paths"] - st.casts / st.paths) < 0.02
+    grp.close()
+    d.set_image(96, 64); d.samples_per_pixel = 5
 
 
 def test_replica_group_on_every_visible_gpu(scenes):

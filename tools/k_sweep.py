@@ -4,7 +4,7 @@
     python tools/k_sweep.py [--scene box] [--size 1440] [--spp 1000] [--reps 2] SPEC [SPEC ...]
 
 SPEC = option=value[:option=value...] (mi_scene_set_option keys), e.g.
-    kernel=1   kernel=3:pool_slots=104:pool_tune=4,48,12,8,4,4
+    kernel=1   kernel=3:pool_waves=8:pool_tune=4,48,12,8,4,4
 Prints one line per spec: ms per frame, casts/s, and whether a 1-in-4099 pixel subsample equals the first spec's."""
 import argparse, sys, time
 from pathlib import Path
