@@ -25,6 +25,21 @@ def arr3(v):
     return (f32 * 3)(*[float(x) for x in v])
 
 
+def blob_case_desc(irl, cnt, case):
+    """A SceneDesc whose eight arrays have the given element counts and seeded random bytes (serialisation does not
+    interpret them), scalars derived from the case number. Returns (desc, keep-alive arrays)."""
+    rng = np.random.default_rng(1000 + case)
+    sizes = (4, 16, 6, 12, 12, 4, 36, 24)
+    arrs = [rng.integers(0, 256, max(c, 1) * sz, dtype=np.uint8) for c, sz in zip(cnt, sizes)]
+    d = irl.SceneDesc()
+    for (ptr, num), a, c in zip((("geometry", "num_geometry"), ("mesh_info", "num_meshes"), ("mesh_tris", "num_tris"), ("mesh_verts", "num_verts"),
+                                  ("mesh_normals", "num_normals"), ("mat_ids", "num_mat_ids"), ("materials", "num_materials"), ("bvh_nodes", "num_nodes")), arrs, cnt):
+        setattr(d, ptr, a.ctypes.data); setattr(d, num, c)
+    d.max_leaf_depth = 3 + case; d.image_width = 100.5 + case; d.image_height = 64.25 * (case + 1); d.fov_radians = 0.7853981852531433
+    d.anti_alias_scale = 0.25 + case / 16; d.max_path_length = 10 + case; d.roulette_start_depth = case % 5; d.samples_per_pixel = 1000 + case
+    return d, arrs
+
+
 def main():
     r = oracle_lib.ref_lib()
     if r is None:
@@ -157,6 +172,38 @@ def main():
         o = (f32 * 9)()
         r.ref_bounds_union((f32 * 6)(*bl[i, 0], *bh[i, 0]), (f32 * 6)(*bl[i, 1], *bh[i, 1]), o); bu[i] = list(o)
     out.update(bounds_lo=bl, bounds_hi=bh, bounds_union=bu)
+
+    # ---- the serialised scene as the reference's own Deserialiser<16> reads it (deserialisation.hpp:31-59) ----
+    # Small synthetic scenes whose array counts put every array on every residue of its alignment; the bytes are
+    # written by the PRODUCT's writer (mi_scene_serialise) and walked by the reference's reader: offsets, counts,
+    # scalars and bytes consumed are the golden values; the blobs themselves are stored so that the test can hand the
+    # very same bytes to the product's reader (and check that the product's writer still produces them).
+    import ipu_ray_lib_amd as irl
+    pad = (C.c_uint32 * 256)(); r.ref_padding_table(pad)
+    out["blob_padding_table"] = np.array(list(pad), np.uint32).reshape(4, 64)
+    blobs, walks, scal, used, counts = [], [], [], [], []
+    brng = np.random.default_rng(77)
+    for case in range(24):
+        cnt = [int(x) for x in brng.integers(0, 7, 8)]
+        if case == 0: cnt = [0] * 8
+        if case == 1: cnt = [1] * 8
+        d, keep = blob_case_desc(irl, cnt, case)
+        blob = irl.serialise_scene(d)
+        w, sc, u = oracle_lib.ref_walk_scene_blob(blob)
+        assert u == blob.size, (case, u, blob.size)
+        blobs.append(blob.copy()); walks.append(w); scal.append(sc); used.append(u); counts.append(cnt)
+    out["blob_case_counts"] = np.array(counts, np.uint32)
+    out["blob_case_sizes"] = np.array([b.size for b in blobs], np.uint32)
+    out["blob_case_bytes"] = np.concatenate(blobs)
+    out["blob_case_walk"] = np.array(walks, np.uint64)
+    out["blob_case_scalars"] = np.array(scal, np.uint32)
+    # truncated streams: the reader must report the end of the byte stream for every proper prefix of case 5
+    b5 = blobs[5]
+    trunc = []
+    for cut in range(0, b5.size):
+        part = irl.aligned_bytes(max(cut, 1))[:cut]; part[:] = b5[:cut]
+        trunc.append(oracle_lib.ref_walk_scene_blob(part)[2] if cut else oracle_lib.ref_walk_scene_blob(irl.aligned_bytes(16)[:0])[2])
+    out["blob_truncation_result"] = np.array(trunc, np.int64)
 
     dst = Path(__file__).with_name("ref_l0_vectors.npz")
     np.savez_compressed(dst, **out)

@@ -158,6 +158,10 @@ def ref_lib():
     r.ref_is_non_zero.argtypes = [pf]; r.ref_is_non_zero.restype = C.c_int
     r.ref_bounds_default.argtypes = [pf]
     r.ref_bounds_union.argtypes = [pf, pf, pf]
+    if hasattr(r, "ref_walk_scene_blob"):
+        r.ref_walk_scene_blob.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+        r.ref_walk_scene_blob.restype = C.c_long
+        r.ref_padding_table.argtypes = [C.POINTER(C.c_uint32)]
     return r
 
 
@@ -204,3 +208,14 @@ def make_nif(kernels, biases, relu, embedding_dimension, max_value, mean, log_to
     nif.halfFeatures = 1 if half_features else 0
     nif.halfWeightsActs = 1 if half_weights_acts else 0
     return nif, [ks, bs, kp, bp, rows, cols, rl]
+
+
+def ref_walk_scene_blob(blob):
+    """The reference's Deserialiser<16> (include/serialisation/Deserialiser.hpp, compiled from the checkout into
+    oracle/_ref) walking a serialised scene: ((offset, count) x 8 arrays, the eight scalars as raw u32, bytes consumed),
+    consumed = -1 when it ran off the end. `blob`: a 16-byte-aligned uint8 numpy array."""
+    r = ref_lib()
+    assert blob.ctypes.data % 16 == 0
+    out = (C.c_uint64 * 16)(); sc = (C.c_uint32 * 8)()
+    used = r.ref_walk_scene_blob(blob.ctypes.data, blob.size, out, sc)
+    return [int(x) for x in out], [int(x) for x in sc], int(used)

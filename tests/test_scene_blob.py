@@ -198,3 +198,98 @@ def test_truncated_and_misaligned_blobs_are_rejected():
     small = np.zeros(16, np.uint8)
     assert lib.mi_scene_serialise(C.byref(s.desc), small.ctypes.data, small.size, None) != 0
     assert lib.mi_scene_blob_size(C.byref(s.desc)) == blob.size
+
+
+# ------------------------------------------------------------------------------------------------------
+# Pinned by the reference's own reader: Deserialiser<16> (include/serialisation/Deserialiser.hpp:14-89) compiled from
+# the checkout (oracle/ref_driver.cpp, ref_walk_scene_blob: deserialiseArrayRef's calls, deserialisation.hpp:31-59,
+# one by one) walked 24 blobs written by mi_scene_serialise; tests/golden/gen_ref_vectors.py stored the blobs and what
+# the reference reader found in them. (GeomRef / MeshInfo / Triangle / CompactBVH2Node cannot be compiled here - Eigen -
+# and stand in that walk as PODs with the alignment their declarations state; Vec3fa, Material and u32 are the
+# reference's own types; the padding rule, the count encoding and the order are its running code throughout.)
+# ------------------------------------------------------------------------------------------------------
+GOLD = np.load(__import__("pathlib").Path(__file__).parent / "golden" / "ref_l0_vectors.npz")
+FIELDS = (("geometry", "num_geometry"), ("mesh_info", "num_meshes"), ("mesh_tris", "num_tris"), ("mesh_verts", "num_verts"),
+          ("mesh_normals", "num_normals"), ("mat_ids", "num_mat_ids"), ("materials", "num_materials"), ("bvh_nodes", "num_nodes"))
+
+
+def _gen_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_ref_vectors", __import__("pathlib").Path(__file__).parent / "golden" / "gen_ref_vectors.py")
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    return m
+
+
+def _product_walk(blob):
+    out = irl.deserialise_scene(blob)
+    walk = []
+    for ptr, num in FIELDS:
+        n = getattr(out, num)
+        p = C.cast(getattr(out, ptr), C.c_void_p).value
+        # (a null pointer is only handed out for an EMPTY normals array; its offset is then not observable)
+        walk += [None if p is None else p - blob.ctypes.data, n]
+    sc = np.array([out.max_leaf_depth, 0, 0, 0, 0, out.max_path_length, out.roulette_start_depth, out.samples_per_pixel], np.uint32)
+    sc[1:5] = np.array([out.image_width, out.image_height, out.fov_radians, out.anti_alias_scale], np.float32).view(np.uint32)
+    return walk, [int(x) for x in sc], out._blob_bytes_used
+
+
+def test_padding_rule_against_the_reference_deserialiser():
+    """Deserialiser<16>::calculatePadding<T>() at every offset 0..63 for alignments 1, 2, 4 (Vec3fa) and 8."""
+    table = GOLD["blob_padding_table"]
+    lib = irl.host_lib()
+    for k, align in enumerate((1, 2, 4, 8)):
+        for off in range(64):
+            assert lib.mi_blob_padding(16, off, align) == table[k, off], (align, off)
+
+
+def test_blob_reader_and_writer_against_the_reference_deserialiser():
+    gen = _gen_module()
+    sizes = GOLD["blob_case_sizes"]; data = GOLD["blob_case_bytes"]; starts = [0] + [int(x) for x in np.cumsum(sizes.astype(np.int64))]
+    node_residues = set()
+    for case, cnt in enumerate(GOLD["blob_case_counts"]):
+        gold = data[starts[case]:starts[case + 1]]
+        # the product's writer still produces the bytes the reference reader was given ...
+        d, keep = gen.blob_case_desc(irl, [int(x) for x in cnt], case)
+        mine = irl.serialise_scene(d)
+        assert mine.tobytes() == gold.tobytes(), f"case {case}: the writer's bytes changed - regenerate the goldens with the reference reader"
+        # ... and the product's reader finds in them what the reference's reader found
+        blob = irl.aligned_bytes(gold.size); blob[:] = gold
+        walk, sc, used = _product_walk(blob)
+        want = [int(x) for x in GOLD["blob_case_walk"][case]]
+        for k in range(8):
+            assert walk[2 * k + 1] == want[2 * k + 1], (case, FIELDS[k][1])
+            if walk[2 * k] is not None:
+                assert walk[2 * k] == want[2 * k], (case, FIELDS[k][0], walk[2 * k], want[2 * k])
+        assert sc == [int(x) for x in GOLD["blob_case_scalars"][case]], case
+        assert used == gold.size == sizes[case]
+        count_at = want[12] + want[13] * 36                # the node count follows the materials (4-aligned already)
+        node_residues.add((want[14] - (count_at + 4), want[14] % 8))
+    assert node_residues == {(0, 0), (4, 0)}              # the node array always starts 8-aligned, after 0 or 4 pad bytes: both cases are in the set
+
+
+def test_truncated_blob_against_the_reference_deserialiser():
+    """Every proper prefix of a blob makes the reference reader throw 'Deserialiser encountered end of byte stream.'
+    (golden: -1 for all of them); the product's reader must refuse exactly those."""
+    sizes = GOLD["blob_case_sizes"]; data = GOLD["blob_case_bytes"]; starts = [0] + [int(x) for x in np.cumsum(sizes.astype(np.int64))]
+    b5 = data[starts[5]:starts[6]]
+    res = GOLD["blob_truncation_result"]
+    assert res.size == b5.size and (res == -1).all()
+    for cut in range(0, b5.size):
+        part = irl.aligned_bytes(max(cut, 1))[:cut]; part[:] = b5[:cut]
+        with pytest.raises(irl.RaylibError, match="Deserialiser encountered end of byte stream"):
+            irl.deserialise_scene(part)
+
+
+def test_real_scene_blobs_against_the_live_reference_deserialiser():
+    """Where oracle/_ref is built (the container that holds the reference checkout): the box scene's and
+    test_scene.dae's blobs through the reference reader, live."""
+    import oracle_lib
+    r = oracle_lib.ref_lib()
+    if r is None or not hasattr(r, "ref_walk_scene_blob"):
+        pytest.skip("oracle/_ref not built here (needs the reference checkout)")
+    for s in (irl.HostScene.builtin("box"), irl.HostScene.import_file(irl.REPO_ROOT / "assets" / "test_scene.dae", load_normals=True)):
+        blob = irl.serialise_scene(s.desc)
+        want, wsc, wused = oracle_lib.ref_walk_scene_blob(blob)
+        walk, sc, used = _product_walk(blob)
+        assert [w for w in walk if w is not None] == [w for w, g in zip(want, walk) if g is not None]
+        assert sc == wsc and used == wused == blob.size
