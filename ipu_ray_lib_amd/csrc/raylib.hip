@@ -78,7 +78,7 @@ const float* hostSinTable() {
 // process-global: creating or tuning scene B never changes what scene A launches.
 struct SceneOptions {
   bool fullStats = false;          // MI_RAYLIB_FULL_STATS / "full_stats": instrumented kernel variants (node/leaf counters, phase occupancy)
-  WaveTune tune = {8, 16, 24, 48, 3};
+  WaveTune tune = kDefaultTune;
   int kernelChoice = 1;            // MI_RAYLIB_KERNEL / "kernel": 0 = nested-loop kernel, 1 = wavefront (global nodes), 2 = wavefront + LDS-staged nodes, 3 = path pool (trace_pool.hpp)
   PoolTune poolTune;               // MI_RAYLIB_POOL_TUNE / "pool_tune": leafAt,burst,retireAt,refillMin,shadeW,genW[,dbl,maxExtra,leafThenNode,prio]
   int poolWaves = 4;               // MI_RAYLIB_POOL_WAVES / "pool_waves": waves per workgroup of the path-pool kernel, 4 | 8 | 16 (400 | 800 | 1600 slots)
@@ -342,6 +342,11 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
     ds.meshNormals = S.keep(upload(std::vector<mi_vec3>(d.mesh_normals, d.mesh_normals + d.num_normals)));
     ds.geomFirstVertex = S.keep(upload(geomFirstVertex));
   }
+  ds.rootInterior = 0;
+  if (N > 1 && !getenv("MI_RAYLIB_NO_ROOT_START")) {      // (N > 1: the root is an interior node - checked above: a leaf root spans one node)
+    ds.rootLoX = nodes[0].minx; ds.rootHiX = nodes[0].maxx; ds.rootLoY = nodes[0].miny; ds.rootHiY = nodes[0].maxy;
+    ds.rootLoZ = nodes[0].minz; ds.rootHiZ = nodes[0].maxz; ds.rootInterior = nodes[0].leaf == kInteriorNode ? 1u : 0u;
+  }
   ds.imageWidth = d.image_width; ds.imageHeight = d.image_height;
   float s, c;
   sincos_deg_table(d.fov_radians / 2.f, hostSinTable(), s, c);   // codelets/TraceCodelets.cpp:147-149
@@ -480,7 +485,10 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
     } else if (!STATS && S.opt.wavesPerSimd == 5) {
       // 96-VGPR build: 5 waves per SIMD (+4.6 % on the box scene; 6 waves = 80 VGPRs: -19 %, its spills land in LEAF/SHADE)
       const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 255) / 256, 256 * 8);
+      const bool fixed = S.opt.tune == kDefaultTune;      // the default weights are compiled into the two default-path instantiations
       if (S.opt.specLeaf) hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, 5, true>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
+      else if (fixed && plain) hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, 5, false, 0, true>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
+      else if (fixed) hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, 5, false, 1, true>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
       else hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, 5>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
     } else {
       const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 255) / 256, 256 * 8);

@@ -61,7 +61,24 @@ struct DeviceScene {
   uint32_t maxPathLength, rouletteStartDepth, samplesPerPixel;
   uint64_t rngSeed;
   unsigned long long* counters;   // [casts, nodes visited, leaf tests, paths]
+  // The root's box, when the root is an interior node (a BVH of more than one node): a ray that starts strictly inside
+  // it hits it, so the walk can start at node 1 (root_start below). rootInterior = 0 switches the shortcut off.
+  float rootLoX, rootLoY, rootLoZ, rootHiX, rootHiY, rootHiZ;
+  uint32_t rootInterior;
 };
+
+// First node of a closest-hit walk with tMin = 0 and tMax = +inf (every cast of the path-trace loop). The reference
+// starts at node 0 (CompactBvh.hpp:95-101) and tests the root's box. For an origin STRICTLY inside that box the test's
+// outcome is known without evaluating it: per axis (min - o) < 0 < (max - o) exactly (the difference of two distinct
+// binary32 numbers never rounds to zero), so whatever the reciprocal direction is - finite, denormal, zero, infinite or
+// NaN - the slab gives tmin <= 0 <= tmax or leaves t0 / t1 untouched (CompactBVH2Node.hpp:14-50: every update is an
+// ordered compare, false for NaN), hence t0 = 0 <= t1 and the box is hit; the root of a BVH with more than one node is an
+// interior node, so the reference's next visit is node 1. Returns that node, and the number of box tests it stands for.
+__device__ __forceinline__ uint32_t root_start(const DeviceScene& sc, f3 o, uint32_t& visited) {
+  const bool inside = (o.x > sc.rootLoX) & (o.x < sc.rootHiX) & (o.y > sc.rootLoY) & (o.y < sc.rootHiY) & (o.z > sc.rootLoZ) & (o.z < sc.rootHiZ) & (sc.rootInterior != 0u);
+  visited = inside ? 1u : 0u;
+  return inside ? 1u : 0u;
+}
 
 struct Shear { uint32_t kz; float sx, sy, sz; };
 

@@ -37,7 +37,8 @@ enum : uint32_t { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_GEN = 3, PH_FETCH =
 //   prio     1: waves run their traversal turns at s_setprio 1 (short dependent steps win VALU arbitration over
 //            another wave's long SHADE/GEN blocks: +1 %), 0: no priorities
 //   leafP    (SPEC build) a LEAF turn also runs once this many lanes hold a pending primitive test
-struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, dbl = 4, maxExtra = 5, leafThenNode = 1, prio = 1, leafP = 40; };
+struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, dbl = 4, maxExtra = 5, leafThenNode = 1, prio = 1, leafP = 40;
+  bool operator==(const WaveTune& o) const { return leafAt == o.leafAt && shadeAt == o.shadeAt && genAt == o.genAt && burst == o.burst && keep8 == o.keep8 && dbl == o.dbl && maxExtra == o.maxExtra && leafThenNode == o.leafThenNode && prio == o.prio && leafP == o.leafP; } };
 
 // Per-launch extras for renders with the NIF environment. The reference traces ONE sample, evaluates the
 // environment for the rays that escaped, adds it, and repeats (src/IpuScene.cpp:571-583). One sample per launch
@@ -76,9 +77,16 @@ struct WaveExtras {
 // primitive found while the first is still pending makes the lane wait as before. Nothing is ever skipped or reordered
 // in what a path finally takes from the walk: only work that turns out to be unnecessary is added, in lanes that
 // would have idled.
-template <bool STATS, bool LDS_NODES, int BLOCK, int WAVES_PER_SIMD = 4, bool SPEC = false>
+// SLOTS: 0 = plain launches only (rgb in registers / partial sums), 1 = NIF launches only (slots), 2 = decided at run time
+// from ex.slotColor. FIXED_TUNE: the scheduling weights are the compile-time defaults (kDefaultTune) instead of the
+// `tune` argument. The two default-path instantiations (<.., 0, true> and <.., 1, true>) carry neither the other mode's
+// code nor the ten weights in scalar registers: no scalar spills (33 before), -2.5 % frame time.
+constexpr WaveTune kDefaultTune = {8, 16, 24, 48, 3, 4, 5, 1, 1, 40};
+template <bool STATS, bool LDS_NODES, int BLOCK, int WAVES_PER_SIMD = 4, bool SPEC = false, int SLOTS = 2, bool FIXED_TUNE = false>
 __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? WAVES_PER_SIMD : 1) path_trace_wavefront_kernel(DeviceScene sc, mi_trace_result* rays, uint32_t n,
-                                                                   uint32_t* workCounter, uint32_t ldsNodeCount, WaveTune tune, uint32_t tileStreamW, WaveExtras ex) {
+                                                                   uint32_t* workCounter, uint32_t ldsNodeCount, WaveTune tuneArg, uint32_t tileStreamW, WaveExtras ex) {
+  const WaveTune tune = FIXED_TUNE ? kDefaultTune : tuneArg;
+  const bool slots = (SLOTS == 2) ? (ex.slotColor != nullptr) : (SLOTS == 1);
   __shared__ float sinTbl[92];
   // the materials a hit is shaded with, when the scene has few (the built-in scenes have 8, test_scene.dae 9): SHADE
   // otherwise waits for two dependent global loads, leaf record then material
@@ -107,7 +115,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
   const uint32_t tiledCount = tileStreamW ? (n / (8u * tileStreamW)) * (8u * tileStreamW) : 0u;
   const uint32_t numNodes = sc.numNodes;
   const uint32_t spp = ex.sampleCount ? ex.sampleCount : sc.samplesPerPixel;
-  const bool segd = ex.segPart != nullptr || ex.slotColor != nullptr;          // (pixel, segment) work atoms
+  const bool segd = ex.segPart != nullptr || slots;          // (pixel, segment) work atoms
   const uint32_t segShift = segment_shift(sc.samplesPerPixel), segMask = (1u << segShift) - 1u;
   const uint32_t segs = segd ? ex.segments : 1u;
   const uint32_t items = n * segs;                 // (host checks that this fits 32 bits)
@@ -189,7 +197,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
           if (seg == 0) { coldF(3) = res->rgb.x; coldF(4) = res->rgb.y; coldF(5) = res->rgb.z; }
           else { coldF(3) = 0.f; coldF(4) = 0.f; coldF(5) = 0.f; }           // a later segment's own partial sum
           rng_seed_pixel_segment(rng, sc.rngSeed, prow, pcol, seg);
-          sample = (ex.slotColor ? seg - ex.segBase : seg) << segShift;      // slots are numbered within the launch
+          sample = (slots ? seg - ex.segBase : seg) << segShift;      // slots are numbered within the launch
           pathStore();                 // (GEN initialises the rest)
           ph = PH_GEN;
         } else {
@@ -436,7 +444,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
         if (terminated) {
           const uint32_t pixNow = getPix();
           mi_trace_result* res = rays + pixNow;
-          if (ex.slotColor) {
+          if (slots) {
             const size_t q = (size_t)sample * n + pixNow;
             ex.slotColor[3 * q] = color.x; ex.slotColor[3 * q + 1] = color.y; ex.slotColor[3 * q + 2] = color.z;
             envRay = (oFlags & MI_FLAG_ESCAPED) != 0;
@@ -449,18 +457,18 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
           if (more) ph = PH_GEN;
           else if (segd && sample < spp) {
             // a segment other than the last is complete: its partial sum (or its slots) is all it leaves
-            if (ex.segPart) {
+            if (!slots && ex.segPart) {
               float* part = ex.segPart + 3 * ((size_t)(((sample - 1u) >> segShift) - ex.segBase) * n + pixNow);
               part[0] = coldF(3); part[1] = coldF(4); part[2] = coldF(5);
             }
             ph = PH_FETCH;
           } else {
             // pixel complete: rgb sum + the LAST sample's hit record
-            if (ex.segPart) {
+            if (!slots && ex.segPart) {
               float* part = ex.segPart + 3 * ((size_t)(((sample - 1u) >> segShift) - ex.segBase) * n + pixNow);
               part[0] = coldF(3); part[1] = coldF(4); part[2] = coldF(5);
             } else
-            if (!ex.slotColor) res->rgb = {coldF(3), coldF(4), coldF(5)};
+            if (!slots) res->rgb = {coldF(3), coldF(4), coldF(5)};
             uint32_t oPrim = MI_INVALID_PRIM, oGeom = MI_INVALID_GEOM;
             const uint32_t lastLeaf = coldU(6);
             if (lastLeaf != 0xFFFFFFFFu) { const GLeaf LL = sc.leaves[lastLeaf]; oPrim = LL.primID; oGeom = leaf_geom(LL); }
@@ -481,13 +489,13 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
           exactSlab = !(fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf && fabsf(o.x) < kInf && fabsf(o.y) < kInf && fabsf(o.z) < kInf);
           sh = make_shear(d, inv);
           hit.t = kInf; hit.leaf = 0xFFFFFFFFu;
-          node = 0;
+          { uint32_t seen; node = root_start(sc, o, seen); if (STATS) cs.nodes += seen; }
           ++casts;
           ph = (numNodes > 0) ? PH_NODE : PH_SHADE;
         }
         pathStore();
       }
-      if (ex.slotColor) {
+      if (slots) {
         const unsigned long long mE = __ballot(envRay);
         if (mE) {
           const uint32_t firstE = (uint32_t)__ffsll((long long)mE) - 1u;
@@ -534,7 +542,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
         exactSlab = !(fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf && fabsf(o.x) < kInf && fabsf(o.y) < kInf && fabsf(o.z) < kInf);
         sh = make_shear(d, inv);
         hit.t = kInf; hit.leaf = 0xFFFFFFFFu;
-        node = 0;
+        { uint32_t seen; node = root_start(sc, o, seen); if (STATS) cs.nodes += seen; }
         ++casts;
         ph = (numNodes > 0) ? PH_NODE : PH_SHADE;
         pathStore();
