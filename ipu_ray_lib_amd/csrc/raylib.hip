@@ -222,6 +222,7 @@ namespace {
 void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
   auto need = [](bool ok, const char* what) { if (!ok) throw ArgError(std::string("mi_scene_create: ") + what); };
   need(d.num_nodes == 0 || d.bvh_nodes, "bvh_nodes is null");
+  need(d.num_nodes < kLeafFlag, "more than 2^31 - 1 BVH nodes");
   need(d.num_geometry == 0 || d.geometry, "geometry is null");
   need(d.num_geometry <= 0xFFFF, "more than 65535 geometries (geomID is 16 bit)");
   need(d.num_mat_ids >= d.num_geometry, "All primitives must be assigned a material.");
@@ -256,7 +257,11 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
   const uint32_t N = d.num_nodes;
   std::vector<GNode> nodes(N);
   std::vector<uint32_t> skip(N);
-  std::vector<GLeaf> leaves;
+  // leaves[] is indexed by NODE: a leaf node's primitive record sits at the node's own index (interior nodes leave a zero
+  // record behind), so the walk never has to carry an index from the box test to the primitive test (trace_wavefront.hpp)
+  std::vector<GLeaf> leaves(N);
+  memset(leaves.data(), 0, leaves.size() * sizeof(GLeaf));
+  std::vector<uint8_t> isLeafNode(N, 0);
   std::vector<uint32_t> geomFirstVertex(d.num_geometry, 0);
   for (uint32_t g = 0; g < d.num_geometry; ++g)
     if (d.geometry[g].type == 0) geomFirstVertex[g] = d.mesh_info[d.geometry[g].index].first_vertex;
@@ -282,7 +287,7 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
     g.maxy = n.min_y + half_bits_to_float(n.dy);
     g.maxz = n.min_z + half_bits_to_float(n.dz);
     g.link = skip[i];
-    g.leaf = kInteriorNode;
+    g.hit = i + 1;                                                 // interior: the first child
     if (n.geom_id != MI_INVALID_GEOM) {
       need(n.geom_id < d.num_geometry, "leaf geomID out of range");
       const mi_geom_ref& r = d.geometry[n.geom_id];
@@ -310,8 +315,9 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
         L.type = LEAF_DISC | ((uint32_t)n.geom_id << 16); L.primID = 0;
       }
       L.matIndex = d.mat_ids[n.geom_id];
-      g.leaf = (uint32_t)leaves.size();
-      leaves.push_back(L);
+      g.hit = skip[i] | kLeafFlag;                                 // leaf: stop in front of link (= i + 1)
+      leaves[i] = L;
+      isLeafNode[i] = 1;
     }
     nodes[i] = g;
   }
@@ -328,7 +334,7 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
     std::vector<float> ln(9 * leaves.size(), 0.f);
     for (size_t k = 0; k < leaves.size(); ++k) {
       const GLeaf& L = leaves[k];
-      if (leaf_kind(L) != LEAF_TRI) continue;
+      if (!isLeafNode[k] || leaf_kind(L) != LEAF_TRI) continue;
       const uint32_t fv = geomFirstVertex[leaf_geom(L)];
       for (int c = 0; c < 3; ++c) {
         const size_t at = (size_t)fv + d.mesh_tris[L.triBase + c];
@@ -345,7 +351,7 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
   ds.rootInterior = 0;
   if (N > 1 && !getenv("MI_RAYLIB_NO_ROOT_START")) {      // (N > 1: the root is an interior node - checked above: a leaf root spans one node)
     ds.rootLoX = nodes[0].minx; ds.rootHiX = nodes[0].maxx; ds.rootLoY = nodes[0].miny; ds.rootHiY = nodes[0].maxy;
-    ds.rootLoZ = nodes[0].minz; ds.rootHiZ = nodes[0].maxz; ds.rootInterior = nodes[0].leaf == kInteriorNode ? 1u : 0u;
+    ds.rootLoZ = nodes[0].minz; ds.rootHiZ = nodes[0].maxz; ds.rootInterior = node_is_leaf(nodes[0]) ? 0u : 1u;
   }
   ds.imageWidth = d.image_width; ds.imageHeight = d.image_height;
   float s, c;

@@ -27,15 +27,20 @@ namespace mi {
 // a 64-bit register pair feeds the packed subtract/multiply directly.
 struct __attribute__((aligned(16))) GNode {
   float minx, maxx, miny, maxy, minz, maxz;
-  uint32_t link;                                  // next(i): where the walk goes on when it does not descend (numNodes = it ends)
-  uint32_t leaf;                                  // index into leaves[]; 0xFFFFFFFF = interior node (its first child is i + 1)
+  uint32_t link;                                  // where the walk goes on when the box is MISSED: next(i), the node after i's subtree in preorder (numNodes = the walk ends)
+  uint32_t hit;                                   // where it goes on when the box is HIT: interior node: i + 1 (its first child); leaf: link | kLeafFlag -
+                                                  // "stop: the primitive of the node BEFORE `link` is to be tested" (a leaf's link is i + 1)
 };
-constexpr uint32_t kInteriorNode = 0xFFFFFFFFu;
+// Both successors precomputed: a box test ends in ONE select (hit ? nd.hit : nd.link), and one unsigned compare with
+// numNodes tells whether the lane walks on - a flagged value is >= 2^31 > numNodes, so "stopped at a primitive" and
+// "walked off the end" both read as "stop" and are told apart once, after a run of box tests, from the flag.
+constexpr uint32_t kLeafFlag = 0x80000000u;
+__host__ __device__ __forceinline__ bool node_is_leaf(const GNode& nd) { return (nd.hit & kLeafFlag) != 0u; }
 static_assert(sizeof(GNode) == 32, "GNode must stay 32 bytes");
 
 enum : uint32_t { LEAF_TRI = 0, LEAF_SPHERE = 1, LEAF_DISC = 2 };
 
-struct __attribute__((aligned(16))) GLeaf {       // 64 B pre-resolved primitive (the primitive test reads the first 48)
+struct __attribute__((aligned(16))) GLeaf {       // 64 B pre-resolved primitive (the primitive test reads the first 48); leaves[i] belongs to leaf NODE i
   float f[9];        // tri: p0,p1,p2 | sphere: cx,cy,cz,radius,radius2 | disc: nx,ny,nz,cx,cy,cz,r2
   uint32_t type;     // LEAF_* in bits 0..15, geomID in bits 16..31
   uint32_t primID;   // value reported in the hit record
@@ -243,10 +248,10 @@ __device__ __forceinline__ bool traverse(const DeviceScene& sc, f3 o, f3 d, floa
       t1 = tmax < t1 ? tmax : t1;
     }
     const bool boxHit = !(t0 > t1);
-    const bool isLeaf = nd.leaf != kInteriorNode;
+    const bool isLeaf = node_is_leaf(nd);
     if (boxHit && isLeaf) {
       if (STATS) cs.leaves++;
-      const GLeaf L = sc.leaves[nd.leaf];
+      const GLeaf L = sc.leaves[i];               // (leaves[] is indexed by node)
       float t, b0 = 0.f, b1 = 0.f, b2 = 0.f;
       bool cand;
       if (leaf_kind(L) == LEAF_TRI) {
@@ -261,7 +266,7 @@ __device__ __forceinline__ bool traverse(const DeviceScene& sc, f3 o, f3 d, floa
       }
       if (cand && t > tMin && t < hit.t) {          // CompactBvh.hpp:124 / :60 (hit.t == ray.tMax for any-hit)
         if (ANY_HIT) return true;
-        hit.t = t; hit.leaf = nd.leaf; hit.geomID = leaf_geom(L); hit.b0 = b0; hit.b1 = b1; hit.b2 = b2;
+        hit.t = t; hit.leaf = i; hit.geomID = leaf_geom(L); hit.b0 = b0; hit.b1 = b1; hit.b2 = b2;
       }
     }
     // next node in the reference's visit order

@@ -232,7 +232,9 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
       bool anyExact = __ballot(exactSlab) != 0ull;
       // One box test of a lane that is in the NODE phase; returns whether the lane is still in it afterwards, so that
       // back-to-back tests narrow the exec mask from that condition directly instead of re-reading `ph`.
-      auto nodeBodyT = [&](auto exactTag) -> bool {
+      // deferTag (the spelled-out run of box tests only): the lane's phase is not updated test by test; the phase of
+      // every lane that took part is derived once, behind the run, from the node value it stopped with.
+      auto nodeBodyT = [&](auto exactTag, auto deferTag) -> bool {
         {
           GNode nd;
           // (uniform base + 32-bit byte offset: the load takes the scalar-base form, one shift instead of 64-bit address math)
@@ -262,13 +264,14 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
             }
           }
           const bool boxHit = !(t0 > t1);
-          const bool isLeaf = nd.leaf != kInteriorNode;
           if (SPEC) {
+            const bool isLeaf = node_is_leaf(nd);
+            const uint32_t here = node;                            // (leaves[] is indexed by node)
             if (STATS) { if (pend1 != 0xFFFFFFFFu) { cs.nodes--; specNodes++; } }
             node = (boxHit && !isLeaf) ? node + 1 : nd.link;      // (a lane always stands at the node BEHIND a primitive it waits for; pend1Node likewise)
             if (boxHit && isLeaf) {
-              if (pend1 != 0xFFFFFFFFu) { pendLeaf = nd.leaf; ph = PH_LEAF; return false; }     // a second one: wait
-              pend1 = nd.leaf; pend1Node = node;                                                // the first one: walk on
+              if (pend1 != 0xFFFFFFFFu) { pendLeaf = here; ph = PH_LEAF; return false; }     // a second one: wait
+              pend1 = here; pend1Node = node;                                                // the first one: walk on
             }
             if (node >= numNodes) {
               if (pend1 != 0xFFFFFFFFu) { pendLeaf = 0xFFFFFFFFu; ph = PH_LEAF; } else ph = PH_SHADE;   // walked to the end with a test pending: wait for it
@@ -276,18 +279,21 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
             }
             return true;
           }
-          pendLeaf = nd.leaf;          // only read while the lane is in PH_LEAF; assigned for every lane so that no merge copy is needed
-          node = (boxHit && !isLeaf) ? node + 1 : nd.link;      // (a lane that waits for a primitive test already stands at the node behind it)
-          if (boxHit && isLeaf) {
-            ph = PH_LEAF;
-            return false;
+          // One select, one compare (GNode: both successors are in the node; a leaf's hit successor carries kLeafFlag and
+          // so reads as "stop"). A lane that stops at a primitive stands at node = leaf + 1 once the flag is taken off:
+          // the record it waits for is leaves[node - 1], nothing is carried from this step to the LEAF turn.
+          node = boxHit ? nd.hit : nd.link;
+          if constexpr (decltype(deferTag)::value) {
+            return node < numNodes;                              // the phase is derived once, behind the run of box tests
+          } else {
+            if (node & kLeafFlag) { node &= ~kLeafFlag; ph = PH_LEAF; return false; }
+            if (node >= numNodes) { ph = PH_SHADE; return false; }
+            return true;
           }
-          if (node >= numNodes) { ph = PH_SHADE; return false; }
-          return true;
         }
       };
-      auto nodeBody = [&]() -> bool { return nodeBodyT(std::false_type{}); };               // the common case: no lane needs the literal test
-      auto nodeStep = [&]() { if (ph == PH_NODE) (void)(anyExact ? nodeBodyT(std::true_type{}) : nodeBodyT(std::false_type{})); };
+      auto nodeBody = [&]() -> bool { return nodeBodyT(std::false_type{}, std::true_type{}); };               // the common case: no lane needs the literal test
+      auto nodeStep = [&]() { if (ph == PH_NODE) (void)(anyExact ? nodeBodyT(std::true_type{}, std::false_type{}) : nodeBodyT(std::false_type{}, std::false_type{})); };
       for (;;) {
         const uint32_t stay = cN;
         const uint32_t cP = SPEC ? (uint32_t)__popcll(__ballot(pend1 != 0xFFFFFFFFu)) : 0u;
@@ -317,6 +323,10 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
                   }
                 }
               }
+            }
+            if (!SPEC) {        // (the SPEC form keeps its own phase bookkeeping, test by test)
+              ph = (node & kLeafFlag) ? PH_LEAF : ((node >= numNodes) ? PH_SHADE : PH_NODE);
+              node &= ~kLeafFlag;
             }
           }
           steps += extra;
@@ -362,7 +372,8 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
           } else
           if (ph == PH_LEAF) {
             if (STATS) cs.leaves++;
-            const GLeaf L = sc.leaves[pendLeaf];
+            const uint32_t atLeaf = node - 1u;          // the leaf the lane stopped at (its link is the node after it)
+            const GLeaf L = sc.leaves[atLeaf];
             float t, b0 = 0.f, b1 = 0.f, b2 = 0.f;
             bool cand;
             const uint32_t kind = leaf_kind(L);
@@ -376,7 +387,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
               t = intersect_disc(L, o, d);
               cand = true;
             }
-            if (cand && t > 0.f && t < hit.t) { hit.t = t; hit.leaf = pendLeaf; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2; }
+            if (cand && t > 0.f && t < hit.t) { hit.t = t; hit.leaf = atLeaf; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2; }
             ph = (node >= numNodes) ? PH_SHADE : PH_NODE;
           }
           // every lane that waited for a primitive test is walking again: the next vote would pick NODE anyway,
