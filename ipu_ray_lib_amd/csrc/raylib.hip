@@ -89,6 +89,9 @@ struct SceneOptions {
   uint32_t nifSamplesPerLaunch = 0;               // MI_RAYLIB_NIF_SPL / "nif_spl": 0 = default (128, memory permitting)
   bool pin = true;                 // MI_RAYLIB_PIN / "pin": page-lock the caller's stream for the duration of mi_render
   uint32_t nifShape = 0;           // MI_RAYLIB_NIF_SHAPE / "nif_shape": 0 = w6 (default), 1 = t6, 2 = t4
+  // the two options that select ARITHMETIC (every other option leaves every result bit alone):
+  bool doubleFallback = false;     // "double_fallback": the reference's ALLOW_DOUBLE_FALLBACK=1 build (CMakeLists.txt:13,34-41; Mesh.cpp:38-51), bit-exact to the oracle in that mode
+  bool fast = false;               // "fast": the tolerance tier (FMA box / triangle tests; plain path-trace renders of the default kernel only)
 
   // Every key takes values from a stated domain; anything else leaves the option as it was and returns false
   // (mi_scene_set_option then reports MI_ERR_INVALID_ARG, as include/mi_raylib.h promises).
@@ -123,6 +126,8 @@ struct SceneOptions {
     if (key == "seg_budget_kb") { if (!number(v, 1, ~0ull >> 12, q)) return false; segBudgetKb = (size_t)q; return true; }
     if (key == "nif_spl") { if (!number(v, 0, 128, q)) return false; nifSamplesPerLaunch = (uint32_t)q; return true; }
     if (key == "pin") return flag01(v, pin);
+    if (key == "double_fallback") return flag01(v, doubleFallback);
+    if (key == "fast") return flag01(v, fast);
     if (key == "nif_shape") {
       const std::string s(v);
       if (s == "w6") nifShape = 0; else if (s == "t6") nifShape = 1; else if (s == "t4") nifShape = 2; else return false;
@@ -141,7 +146,8 @@ struct SceneOptions {
     static const char* const map[][2] = {{"MI_RAYLIB_FULL_STATS", "full_stats"}, {"MI_RAYLIB_KERNEL", "kernel"}, {"MI_RAYLIB_WAVES", "waves"}, {"MI_RAYLIB_SPEC", "spec"},
                                          {"MI_RAYLIB_SEG_BUDGET_KB", "seg_budget_kb"}, {"MI_RAYLIB_NIF_SPL", "nif_spl"}, {"MI_RAYLIB_PIN", "pin"},
                                          {"MI_RAYLIB_NIF_SHAPE", "nif_shape"}, {"MI_RAYLIB_TUNE", "tune"},
-                                         {"MI_RAYLIB_POOL_TUNE", "pool_tune"}, {"MI_RAYLIB_POOL_WAVES", "pool_waves"}};
+                                         {"MI_RAYLIB_POOL_TUNE", "pool_tune"}, {"MI_RAYLIB_POOL_WAVES", "pool_waves"},
+                                         {"MI_RAYLIB_DOUBLE_FALLBACK", "double_fallback"}, {"MI_RAYLIB_FAST", "fast"}};
     // (an unparsable environment value is ignored: the option keeps its default)
     for (const auto& m : map) if (const char* e = getenv(m[0])) (void)set(m[1], e);
     if (getenv("MI_RAYLIB_NO_TILES")) tiles = false;
@@ -453,7 +459,15 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
     HIP_CHECK(hipMemsetAsync(workCounter, 0, sizeof(uint32_t), stream));
     const uint64_t items = (uint64_t)cnt * ((segmented || !plain) ? exs.segments : 1u);     // work atoms of this launch
     if (items > kMaxWorkItems) throw ArgError("mi_render: too many work items for one launch (cut the stream with mi_scene_set_ray_batch)");
-    if (S.opt.kernelChoice == 3 && S.ds.samplesPerPixel <= kPoolMaxSamples && S.ds.maxPathLength <= kPoolMaxBounces) {
+    if (S.opt.doubleFallback) {
+      // the ALLOW_DOUBLE_FALLBACK=1 variant: the phase-scheduled kernel's 4-wave build with the binary64 edge functions compiled in
+      const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 255) / 256, 256 * 8);
+      hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, 4, false, 2, false, true>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
+    } else if (S.opt.fast && plain && !STATS) {
+      // the tolerance tier (never the default): FMA box and triangle tests
+      const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 255) / 256, 256 * 8);
+      hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, 5, false, 0, true, false, true>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
+    } else if (S.opt.kernelChoice == 3 && S.ds.samplesPerPixel <= kPoolMaxSamples && S.ds.maxPathLength <= kPoolMaxBounces) {
       // path pool (trace_pool.hpp): persistent, exactly as many workgroups as stay resident; a workgroup of W waves
       // owns 100 W path slots
       const uint32_t W = (uint32_t)S.opt.poolWaves, pwg = 100u * W;
@@ -512,10 +526,13 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
   const dim3 block(256), grid((cnt + 255) / 256);
   if (mode == MI_MODE_SHADOW_TRACE) {
     const f3 light = mk(18.f, 257.f, -1060.f);          // trace.cpp:247, src/IpuScene.cpp:447
-    if (S.opt.fullStats) hipLaunchKernelGGL(shadow_trace_kernel<true>, grid, block, 0, stream, S.ds, d_rays, cnt, .05f, light);
+    if (S.opt.doubleFallback) hipLaunchKernelGGL((shadow_trace_kernel<false, true>), grid, block, 0, stream, S.ds, d_rays, cnt, .05f, light);
+    else if (S.opt.fullStats) hipLaunchKernelGGL(shadow_trace_kernel<true>, grid, block, 0, stream, S.ds, d_rays, cnt, .05f, light);
     else hipLaunchKernelGGL(shadow_trace_kernel<false>, grid, block, 0, stream, S.ds, d_rays, cnt, .05f, light);
   } else if (mode == MI_MODE_PATH_TRACE) {
-    if (!S.nif.loaded() && S.opt.kernelChoice != 0 && S.ds.samplesPerPixel >= 1 && S.ds.maxPathLength >= 1) {
+    // (the ALLOW_DOUBLE_FALLBACK=1 variant is compiled into the phase-scheduled kernel and the shadow kernel: it always takes them)
+    const bool nested = S.opt.kernelChoice == 0 && !S.opt.doubleFallback;
+    if (!S.nif.loaded() && !nested && S.ds.samplesPerPixel >= 1 && S.ds.maxPathLength >= 1) {
       // sample loop inside the kernel (src/IpuScene.cpp:441), phase-scheduled persistent form
       if (S.opt.fullStats) launchWavefront<true>(S, d_rays, cnt, stream);
       else launchWavefront<false>(S, d_rays, cnt, stream);
@@ -531,7 +548,7 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
       if (S.nifPending) HIP_CHECK(hipStreamWaitEvent(stream, S.nifDone, 0));
       ensureScratch(S, n);
       const float radians = (S.hdriRotationDegrees / 360.f) * (float)(2.0 * M_PI);   // src/IpuScene.cpp:644
-      const bool wave = S.opt.kernelChoice != 0 && S.ds.maxPathLength >= 1;
+      const bool wave = !nested && S.ds.maxPathLength >= 1;
       if (wave) {
         // persistent phase-scheduled kernel, several samples per launch; every path leaves a slot (WaveExtras), the
         // MLP runs on the compacted escaped slots, and a per-pixel pass adds everything in the reference's order

@@ -122,7 +122,10 @@ __device__ __forceinline__ f3 permute_kz(f3 p, uint32_t kz) {
   return mk(r1 ? p.y : (r2 ? p.z : p.x), r1 ? p.z : (r2 ? p.x : p.y), r1 ? p.x : (r2 ? p.y : p.z));
 }
 
-// Mesh.cpp:6-104 (ALLOW_DOUBLE_FALLBACK=0), tFar = inf as passed by Mesh.hpp:92. Returns t (0 = miss).
+// Mesh.cpp:6-104, tFar = inf as passed by Mesh.hpp:92. Returns t (0 = miss). DF = the reference's compile-time variant
+// ALLOW_DOUBLE_FALLBACK=1 (CMakeLists.txt:13,34-41; Mesh.cpp:38-51): when an edge function is exactly zero all three are
+// recomputed from products and differences in binary64 and narrowed to binary32 (v_mul_f64 / v_add_f64 / v_cvt_f32_f64
+// are IEEE operations: the same bits as the host's doubles). DF = false is the reference default.
 // Written without the reference's early returns: every lane runs every operation and the verdicts are combined at the
 // end. Identical values for every input, NaNs included: each early return of Mesh.cpp is a predicate that is evaluated
 // here on the same operands (a lane that would have returned early computes on - with whatever its operands give, an
@@ -130,14 +133,28 @@ __device__ __forceinline__ f3 permute_kz(f3 p, uint32_t kz) {
 // +inf (det>0), and "tScaled < -inf" / "tScaled > +inf" are false for every float including NaN, so those two
 // comparisons of Mesh.cpp:62-66 drop out exactly. Measured against the early-return form: -1.4 % frame time (hipcc
 // turns early returns into nested exec regions whose merges cost 45 register moves per test).
+template <bool DF = false>
 __device__ __forceinline__ float intersect_triangle(f3 p0, f3 p1, f3 p2, f3 o, const Shear& sh, float& b0, float& b1, float& b2) {
   f3 p0t = permute_kz(p0 - o, sh.kz), p1t = permute_kz(p1 - o, sh.kz), p2t = permute_kz(p2 - o, sh.kz);
   p0t.x += sh.sx * p0t.z; p0t.y += sh.sy * p0t.z;
   p1t.x += sh.sx * p1t.z; p1t.y += sh.sy * p1t.z;
   p2t.x += sh.sx * p2t.z; p2t.y += sh.sy * p2t.z;
-  const float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
-  const float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
-  const float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+  float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+  float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+  float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+  if constexpr (DF) {
+    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {             // Mesh.cpp:40-50, operation for operation
+      const double p2txp1ty = (double)p2t.x * (double)p1t.y;
+      const double p2typ1tx = (double)p2t.y * (double)p1t.x;
+      e0 = (float)(p2typ1tx - p2txp1ty);
+      const double p0txp2ty = (double)p0t.x * (double)p2t.y;
+      const double p0typ2tx = (double)p0t.y * (double)p2t.x;
+      e1 = (float)(p0typ2tx - p0txp2ty);
+      const double p1txp0ty = (double)p1t.x * (double)p0t.y;
+      const double p1typ0tx = (double)p1t.y * (double)p0t.x;
+      e2 = (float)(p1typ0tx - p1txp0ty);
+    }
+  }
   // (bitwise, not short-circuit: with || hipcc rebuilds the early returns as nested exec regions; -0.4 % frame time)
 #define MI_OR |
 #define MI_AND &
@@ -159,6 +176,42 @@ __device__ __forceinline__ float intersect_triangle(f3 p0, f3 p1, f3 p2, f3 o, c
   const float deltaE = 2 * (gamma_n(2) * maxXt * maxYt + deltaY * maxXt + deltaX * maxYt);
   const float maxE = min_comp(abs3(mk(e0, e1, e2)));
   const float deltaT = 3 * (gamma_n(3) * maxE * maxZt + deltaE * maxZt + deltaZ * maxE) * fabsf(invDet);
+  miss = miss MI_OR (t <= deltaT);
+  return miss ? 0.f : t;
+}
+
+// The TOLERANCE tier's triangle test (scene option "fast" = 1; never the default, never the headline): the same test
+// with floating-point contraction allowed (the shear, the edge functions, tScaled and the error bound fuse into FMAs)
+// and the determinant's reciprocal taken with v_rcp_f32 (1 ulp) instead of the correctly rounded division. t, the
+// barycentrics and the accept / reject verdict then differ from the exact tier's by a few ulp at most - stated and
+// tested as a tolerance (tests/test_gpu_parity.py, test_fast_tier_*), not as parity.
+__device__ __forceinline__ float intersect_triangle_fast(f3 p0, f3 p1, f3 p2, f3 o, const Shear& sh, float& b0, float& b1, float& b2) {
+#pragma clang fp contract(fast)
+  f3 p0t = permute_kz(p0 - o, sh.kz), p1t = permute_kz(p1 - o, sh.kz), p2t = permute_kz(p2 - o, sh.kz);
+  p0t.x = __builtin_fmaf(sh.sx, p0t.z, p0t.x); p0t.y = __builtin_fmaf(sh.sy, p0t.z, p0t.y);
+  p1t.x = __builtin_fmaf(sh.sx, p1t.z, p1t.x); p1t.y = __builtin_fmaf(sh.sy, p1t.z, p1t.y);
+  p2t.x = __builtin_fmaf(sh.sx, p2t.z, p2t.x); p2t.y = __builtin_fmaf(sh.sy, p2t.z, p2t.y);
+  const float e0 = __builtin_fmaf(p1t.x, p2t.y, -(p1t.y * p2t.x));
+  const float e1 = __builtin_fmaf(p2t.x, p0t.y, -(p2t.y * p0t.x));
+  const float e2 = __builtin_fmaf(p0t.x, p1t.y, -(p0t.y * p1t.x));
+  bool miss = ((e0 < 0) MI_OR (e1 < 0) MI_OR (e2 < 0)) MI_AND ((e0 > 0) MI_OR (e1 > 0) MI_OR (e2 > 0));
+  const float det = e0 + e1 + e2;
+  miss = miss MI_OR (det == 0);
+  p0t.z *= sh.sz; p1t.z *= sh.sz; p2t.z *= sh.sz;
+  const float tScaled = __builtin_fmaf(e0, p0t.z, __builtin_fmaf(e1, p1t.z, e2 * p2t.z));
+  miss = miss MI_OR ((det < 0.f) MI_AND (tScaled >= 0.f)) MI_OR ((det > 0.f) MI_AND (tScaled <= 0.f));
+  const float invDet = __builtin_amdgcn_rcpf(det);
+  b0 = e0 * invDet; b1 = e1 * invDet; b2 = e2 * invDet;
+  const float t = tScaled * invDet;
+  const float maxZt = min_comp(abs3(mk(p0t.z, p1t.z, p2t.z)));
+  const float deltaZ = gamma_n(3) * maxZt;
+  const float maxXt = min_comp(abs3(mk(p0t.x, p1t.x, p2t.x)));
+  const float maxYt = min_comp(abs3(mk(p0t.y, p1t.y, p2t.y)));
+  const float deltaX = gamma_n(5) * (maxXt + maxZt);
+  const float deltaY = gamma_n(5) * (maxYt + maxZt);
+  const float deltaE = 2 * __builtin_fmaf(gamma_n(2) * maxXt, maxYt, __builtin_fmaf(deltaY, maxXt, deltaX * maxYt));
+  const float maxE = min_comp(abs3(mk(e0, e1, e2)));
+  const float deltaT = 3 * __builtin_fmaf(gamma_n(3) * maxE, maxZt, __builtin_fmaf(deltaE, maxZt, deltaZ * maxE)) * fabsf(invDet);
   miss = miss MI_OR (t <= deltaT);
 #undef MI_OR
 #undef MI_AND
@@ -215,7 +268,7 @@ struct CastStats { uint32_t nodes, leaves; };
 // Box test: CompactBVH2Node.cpp:5-22 + intersectRaySlab (CompactBVH2Node.hpp:14-50). All three
 // slabs are evaluated before the single t0>t1 test; since t0 only grows and t1 only shrinks across
 // the axes, that is the same predicate as the reference's per-axis early outs.
-template <bool ANY_HIT, bool STATS>
+template <bool ANY_HIT, bool STATS, bool DF = false>
 __device__ __forceinline__ bool traverse(const DeviceScene& sc, f3 o, f3 d, float tMin, float tMax, Hit& hit, CastStats& cs) {
   const f3 inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
   const Shear sh = make_shear(d);
@@ -255,7 +308,7 @@ __device__ __forceinline__ bool traverse(const DeviceScene& sc, f3 o, f3 d, floa
       float t, b0 = 0.f, b1 = 0.f, b2 = 0.f;
       bool cand;
       if (leaf_kind(L) == LEAF_TRI) {
-        t = intersect_triangle(mk(L.f[0], L.f[1], L.f[2]), mk(L.f[3], L.f[4], L.f[5]), mk(L.f[6], L.f[7], L.f[8]), o, sh, b0, b1, b2);
+        t = intersect_triangle<DF>(mk(L.f[0], L.f[1], L.f[2]), mk(L.f[3], L.f[4], L.f[5]), mk(L.f[6], L.f[7], L.f[8]), o, sh, b0, b1, b2);
         cand = t > 0.f && t < kInf;                 // Mesh.hpp:93
       } else if (leaf_kind(L) == LEAF_SPHERE) {
         t = intersect_sphere(L, o, d, tMin);
@@ -312,7 +365,7 @@ __device__ __forceinline__ void load_sin_table(float* tbl) {
 }
 
 // ---- K2: shadow trace ---------------------------------------------------------------------------------
-template <bool STATS>
+template <bool STATS, bool DF = false>
 __global__ void __launch_bounds__(256) shadow_trace_kernel(DeviceScene sc, mi_trace_result* rays, uint32_t n, float ambient, f3 lightPos) {
   const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
   CastStats cs = {0, 0};
@@ -323,7 +376,7 @@ __global__ void __launch_bounds__(256) shadow_trace_kernel(DeviceScene sc, mi_tr
     f3 o = mk(h.r.origin.x, h.r.origin.y, h.r.origin.z), d = mk(h.r.direction.x, h.r.direction.y, h.r.direction.z);
     Hit hit;
     ++casts;
-    if (traverse<false, STATS>(sc, o, d, h.r.t_min, h.r.t_max, hit, cs)) {
+    if (traverse<false, STATS, DF>(sc, o, d, h.r.t_min, h.r.t_max, hit, cs)) {
       // updateHit, Render.hpp:15-23
       const f3 hp = o + d * hit.t;
       const f3 nrm = hit_normal(sc, hit, hp);
@@ -336,7 +389,7 @@ __global__ void __launch_bounds__(256) shadow_trace_kernel(DeviceScene sc, mi_tr
       f3 color = albedo * ambient;
       Hit shadowHit;
       ++casts;
-      if (!traverse<true, STATS>(sc, so, sd, 0.f, sTmax, shadowHit, cs)) color = color + albedo * dot(sd, nrm);
+      if (!traverse<true, STATS, DF>(sc, so, sd, 0.f, sTmax, shadowHit, cs)) color = color + albedo * dot(sd, nrm);
       res->rgb = {color.x, color.y, color.z};
       res->h.r.origin = {hp.x, hp.y, hp.z};
       res->h.r.t_max = hit.t;
@@ -360,7 +413,7 @@ struct PathState {
   uint32_t primID, geomID, flags;
 };
 
-template <bool STATS>
+template <bool STATS, bool DF = false>
 __global__ void __launch_bounds__(256) path_trace_kernel(DeviceScene sc, mi_trace_result* rays, uint32_t n, uint32_t firstSample, uint32_t numSamples, Rng* rngStates) {
   __shared__ float sinTbl[92];
   load_sin_table(sinTbl);
@@ -405,7 +458,7 @@ __global__ void __launch_bounds__(256) path_trace_kernel(DeviceScene sc, mi_trac
         ps.o = offset_origin(ps.o, ps.d, ps.n);
         Hit hit;
         ++casts;
-        if (traverse<false, STATS>(sc, ps.o, ps.d, 0.f, kInf, hit, cs)) {
+        if (traverse<false, STATS, DF>(sc, ps.o, ps.d, 0.f, kInf, hit, cs)) {
           // updateHit
           ps.geomID = hit.geomID;
           ps.primID = sc.leaves[hit.leaf].primID;

@@ -82,7 +82,10 @@ struct WaveExtras {
 // `tune` argument. The two default-path instantiations (<.., 0, true> and <.., 1, true>) carry neither the other mode's
 // code nor the ten weights in scalar registers: no scalar spills (33 before), -2.5 % frame time.
 constexpr WaveTune kDefaultTune = {8, 16, 24, 48, 3, 4, 5, 1, 1, 40};
-template <bool STATS, bool LDS_NODES, int BLOCK, int WAVES_PER_SIMD = 4, bool SPEC = false, int SLOTS = 2, bool FIXED_TUNE = false>
+// DF: the reference's ALLOW_DOUBLE_FALLBACK=1 build of the triangle test (trace_kernels.hpp). FAST: the tolerance tier
+// (scene option "fast"): the box test as three pairs of FMAs on (plane, 1/d, -o/d), the triangle test contracted, no
+// literal NaN-exact fallback - results within a stated tolerance of the exact tier's, not bit-identical.
+template <bool STATS, bool LDS_NODES, int BLOCK, int WAVES_PER_SIMD = 4, bool SPEC = false, int SLOTS = 2, bool FIXED_TUNE = false, bool DF = false, bool FAST = false>
 __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? WAVES_PER_SIMD : 1) path_trace_wavefront_kernel(DeviceScene sc, mi_trace_result* rays, uint32_t n,
                                                                    uint32_t* workCounter, uint32_t ldsNodeCount, WaveTune tuneArg, uint32_t tileStreamW, WaveExtras ex) {
   const WaveTune tune = FIXED_TUNE ? kDefaultTune : tuneArg;
@@ -128,6 +131,8 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
   Rng rng; rng.s0 = rng.s1 = 0;
   f3 color = mk(0, 0, 0), tp = mk(1, 1, 1);
   f3 o = mk(0, 0, 0), d = mk(0, 0, -1), nrm = mk(0, 0, 1), inv = mk(0, 0, 0);
+  f3 oi = mk(0, 0, 0);           // FAST only: -o * inv, the constant term of the box test's FMAs
+  float slabPad = 0.f;           // FAST only: what the far side is widened by (below)
   Shear sh; sh.kz = 2; sh.sx = sh.sy = 0.f; sh.sz = 1.f;
   Hit hit; hit.t = kInf; hit.leaf = 0xFFFFFFFFu; hit.geomID = 0xFFFFu; hit.b0 = hit.b1 = hit.b2 = 0.f;
   uint32_t oFlags = 0;
@@ -229,7 +234,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
       uint32_t steps = 0;
       // lanes only change rays in SHADE/GEN, so "some lane needs the literal box test" is a
       // per-burst fact
-      bool anyExact = __ballot(exactSlab) != 0ull;
+      bool anyExact = !FAST && __ballot(exactSlab) != 0ull;
       // One box test of a lane that is in the NODE phase; returns whether the lane is still in it afterwards, so that
       // back-to-back tests narrow the exec mask from that condition directly instead of re-reading `ph`.
       // deferTag (the spelled-out run of box tests only): the lane's phase is not updated test by test; the phase of
@@ -250,11 +255,24 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
           // reference's literal compare/select sequence below, so NaN cases stay bit-identical too.
           // The far side is scaled ONCE: x -> fl(x * kSlabScale) is monotone non-decreasing, so
           // min(fl(bx*s), fl(by*s), fl(bz*s)) == fl(min(bx, by, bz) * s) bit for bit (no NaNs on this path).
-          const float ax = (nd.minx - o.x) * inv.x, bx = (nd.maxx - o.x) * inv.x;
-          const float ay = (nd.miny - o.y) * inv.y, by = (nd.maxy - o.y) * inv.y;
-          const float az = (nd.minz - o.z) * inv.z, bz = (nd.maxz - o.z) * inv.z;
+          float ax, bx, ay, by, az, bz;
+          if constexpr (FAST) {
+            ax = __builtin_fmaf(nd.minx, inv.x, oi.x); bx = __builtin_fmaf(nd.maxx, inv.x, oi.x);
+            ay = __builtin_fmaf(nd.miny, inv.y, oi.y); by = __builtin_fmaf(nd.maxy, inv.y, oi.y);
+            az = __builtin_fmaf(nd.minz, inv.z, oi.z); bz = __builtin_fmaf(nd.maxz, inv.z, oi.z);
+          } else {
+            ax = (nd.minx - o.x) * inv.x; bx = (nd.maxx - o.x) * inv.x;
+            ay = (nd.miny - o.y) * inv.y; by = (nd.maxy - o.y) * inv.y;
+            az = (nd.minz - o.z) * inv.z; bz = (nd.maxz - o.z) * inv.z;
+          }
           float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
-          float t1 = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * kSlabScale, hit.t);
+          // FAST: fma(plane, 1/d, -o/d) carries an ABSOLUTE error of about eps * |o/d| (the two terms cancel), far more than
+          // the eps * |t| of the exact tier's (plane - o) * (1/d) and more than the 1 + 2 gamma(3) scale covers: 0.6 % of the
+          // box scene's pixels lost a hit to a falsely missed box. The far side is therefore widened by 8 eps * max |o/d|
+          // (slabPad, per cast) - inside the instruction that applies the scale, so the test stays as cheap and errs on
+          // the side of visiting.
+          float t1 = FAST ? fminf(__builtin_fmaf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)), kSlabScale, slabPad), hit.t)
+                          : fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * kSlabScale, hit.t);
           if constexpr (decltype(exactTag)::value) {
             if (exactSlab) {
               t0 = 0.f; t1 = hit.t;
@@ -341,7 +359,8 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
               bool cand;
               const uint32_t kind = leaf_kind(L);
               if (kind == LEAF_TRI) {
-                t = intersect_triangle(mk(L.f[0], L.f[1], L.f[2]), mk(L.f[3], L.f[4], L.f[5]), mk(L.f[6], L.f[7], L.f[8]), o, sh, b0, b1, b2);
+                t = FAST ? intersect_triangle_fast(mk(L.f[0], L.f[1], L.f[2]), mk(L.f[3], L.f[4], L.f[5]), mk(L.f[6], L.f[7], L.f[8]), o, sh, b0, b1, b2)
+                       : intersect_triangle<DF>(mk(L.f[0], L.f[1], L.f[2]), mk(L.f[3], L.f[4], L.f[5]), mk(L.f[6], L.f[7], L.f[8]), o, sh, b0, b1, b2);
                 cand = t > 0.f && t < kInf;
               } else if (kind == LEAF_SPHERE) {
                 t = intersect_sphere(L, o, d, 0.f);
@@ -378,7 +397,8 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
             bool cand;
             const uint32_t kind = leaf_kind(L);
             if (kind == LEAF_TRI) {
-              t = intersect_triangle(mk(L.f[0], L.f[1], L.f[2]), mk(L.f[3], L.f[4], L.f[5]), mk(L.f[6], L.f[7], L.f[8]), o, sh, b0, b1, b2);
+              t = FAST ? intersect_triangle_fast(mk(L.f[0], L.f[1], L.f[2]), mk(L.f[3], L.f[4], L.f[5]), mk(L.f[6], L.f[7], L.f[8]), o, sh, b0, b1, b2)
+                       : intersect_triangle<DF>(mk(L.f[0], L.f[1], L.f[2]), mk(L.f[3], L.f[4], L.f[5]), mk(L.f[6], L.f[7], L.f[8]), o, sh, b0, b1, b2);
               cand = t > 0.f && t < kInf;
             } else if (kind == LEAF_SPHERE) {
               t = intersect_sphere(L, o, d, 0.f);
@@ -499,6 +519,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
           inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
           exactSlab = !(fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf && fabsf(o.x) < kInf && fabsf(o.y) < kInf && fabsf(o.z) < kInf);
           sh = make_shear(d, inv);
+          if (FAST) { oi = mk(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z)); slabPad = 4.8e-7f * fmaxf(fmaxf(fabsf(oi.x), fabsf(oi.y)), fabsf(oi.z)); }
           hit.t = kInf; hit.leaf = 0xFFFFFFFFu;
           { uint32_t seen; node = root_start(sc, o, seen); if (STATS) cs.nodes += seen; }
           ++casts;
@@ -552,6 +573,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
         inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
         exactSlab = !(fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf && fabsf(o.x) < kInf && fabsf(o.y) < kInf && fabsf(o.z) < kInf);
         sh = make_shear(d, inv);
+        if (FAST) { oi = mk(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z)); slabPad = 4.8e-7f * fmaxf(fmaxf(fabsf(oi.x), fabsf(oi.y)), fabsf(oi.z)); }
         hit.t = kInf; hit.leaf = 0xFFFFFFFFu;
         { uint32_t seen; node = root_start(sc, o, seen); if (STATS) cs.nodes += seen; }
         ++casts;

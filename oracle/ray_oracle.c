@@ -313,7 +313,13 @@ void o_ray_shear(const oray* ray, oshear* tf) {
   tf->sz = 1.f / d.z;
 }
 
-/* Mesh.cpp:6-104, ALLOW_DOUBLE_FALLBACK == 0 (reference default, CMakeLists.txt:13). [PROBE]
+/* The reference's compile-time variant ALLOW_DOUBLE_FALLBACK (CMakeLists.txt:13,34-41: a -D flag of the whole build,
+ * default 0) as a process-wide switch of this test library: 0 = the default build, 1 = Mesh.cpp:38-51 compiled in. */
+static int g_double_fallback = 0;
+void o_set_double_fallback(int on) { g_double_fallback = on ? 1 : 0; }
+int o_get_double_fallback(void) { return g_double_fallback; }
+
+/* Mesh.cpp:6-104; ALLOW_DOUBLE_FALLBACK == 0 is the reference default (CMakeLists.txt:13). [PROBE]
  * Returns t (0.f == miss); bary always receives b0,b1,b2 when the determinant test passed. */
 float o_intersect_triangle(ovec3 p0, ovec3 p1, ovec3 p2, const oshear* tf, float tFar, float bary[3]) {
   bary[0] = bary[1] = bary[2] = 0.f;
@@ -327,6 +333,20 @@ float o_intersect_triangle(ovec3 p0, ovec3 p1, ovec3 p2, const oshear* tf, float
   float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
   float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
   float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+  if (g_double_fallback) {
+    /* Mesh.cpp:38-51: fall back to double precision for edge cases */
+    if ((e0 == 0.0f || e1 == 0.0f || e2 == 0.0f)) {
+      double p2txp1ty = (double)p2t.x * (double)p1t.y;
+      double p2typ1tx = (double)p2t.y * (double)p1t.x;
+      e0 = (float)(p2typ1tx - p2txp1ty);
+      double p0txp2ty = (double)p0t.x * (double)p2t.y;
+      double p0typ2tx = (double)p0t.y * (double)p2t.x;
+      e1 = (float)(p0typ2tx - p0txp2ty);
+      double p1txp0ty = (double)p1t.x * (double)p0t.y;
+      double p1typ0tx = (double)p1t.y * (double)p0t.x;
+      e2 = (float)(p1typ0tx - p1txp0ty);
+    }
+  }
   if ((e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0)) return 0.f;
   float det = e0 + e1 + e2;
   if (det == 0) return 0.f;

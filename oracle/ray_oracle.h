@@ -100,6 +100,9 @@ typedef struct { ovec3 o; ovec3 dir; uint32_t ix, iy, iz; float sx, sy, sz; } os
 void o_ray_shear(const oray* ray, oshear* out);          /* Primitives.cpp:5-22 */
 /* returns t (0 = miss) and barycentrics; Mesh.cpp:6-104 with ALLOW_DOUBLE_FALLBACK=0 */
 float o_intersect_triangle(ovec3 p0, ovec3 p1, ovec3 p2, const oshear* tf, float tFar, float bary[3]);
+/* ALLOW_DOUBLE_FALLBACK (CMakeLists.txt:13,34-41; Mesh.cpp:38-51) as a process-wide switch of this library: 0 (default) / 1 */
+void o_set_double_fallback(int on);
+int o_get_double_fallback(void);
 float o_sphere_intersect(const osphere* s, const oray* ray);   /* Primitives.cpp:24-47; 0 = miss */
 float o_disc_intersect(const odisc* d, const oray* ray);       /* Primitives.cpp:49-67; 0 = miss */
 

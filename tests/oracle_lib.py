@@ -90,6 +90,7 @@ def lib():
     o.o_node_intersect.argtypes = [C.POINTER(Node), Vec3, Vec3, pf, pf]; o.o_node_intersect.restype = C.c_int
     o.o_ray_shear.argtypes = [C.POINTER(Ray), C.POINTER(Shear)]
     o.o_intersect_triangle.argtypes = [Vec3, Vec3, Vec3, C.POINTER(Shear), f32, pf]; o.o_intersect_triangle.restype = f32
+    o.o_set_double_fallback.argtypes = [C.c_int]; o.o_set_double_fallback.restype = None
     o.o_sphere_intersect.argtypes = [C.POINTER(Sphere), C.POINTER(Ray)]; o.o_sphere_intersect.restype = f32
     o.o_disc_intersect.argtypes = [C.POINTER(Disc), C.POINTER(Ray)]; o.o_disc_intersect.restype = f32
     o.o_offset_ray.argtypes = [C.POINTER(Ray), Vec3]
@@ -219,3 +220,11 @@ def ref_walk_scene_blob(blob):
     out = (C.c_uint64 * 16)(); sc = (C.c_uint32 * 8)()
     used = r.ref_walk_scene_blob(blob.ctypes.data, blob.size, out, sc)
     return [int(x) for x in out], [int(x) for x in sc], int(used)
+
+
+class double_fallback:
+    """with oracle_lib.double_fallback(): ... - the oracle as the reference's ALLOW_DOUBLE_FALLBACK=1 build (Mesh.cpp:38-51)."""
+    def __enter__(self):
+        lib().o_set_double_fallback(1)
+    def __exit__(self, *a):
+        lib().o_set_double_fallback(0)

@@ -1056,3 +1056,157 @@ def test_nif_escaped_ray_with_nan_environment_coordinate(scenes):
     for kernel in ("1", "3"):
         assert_streams_identical(render(kernel), literal, f"NaN environment coordinate, kernel {kernel}")
     d.set_image(96, 64); d.samples_per_pixel = 5; d.rng_seed = 1442; d.anti_alias_scale = 0.25; d.max_path_length = 10; d.roulette_start_depth = 3
+
+
+# ------------------------------------------------------------------------------------------------------
+# the two options that select ARITHMETIC: the reference's ALLOW_DOUBLE_FALLBACK=1 build (bit exact to the oracle in
+# that mode) and the tolerance tier "fast" (FMA box / triangle tests; a stated tolerance, not parity)
+# ------------------------------------------------------------------------------------------------------
+def _grazing_scene(rng, n_tris):
+    """Triangles stacked along -z, each with an edge whose float edge function is (nearly always) exactly zero for the
+    ray (0,0,0) -> (0,0,-1) while the exact value is not: p2.xy = fl(k * p1.xy), k < 0, so the ray passes through the
+    edge p1-p2 up to rounding. Mesh.cpp:38-51 (ALLOW_DOUBLE_FALLBACK=1) decides those cases in binary64."""
+    v = np.zeros(3 * n_tris, dtype=irl.VEC3)
+    for i in range(n_tris):
+        p1 = rng.uniform(0.5, 2.0, 2).astype(np.float32) * rng.choice([-1, 1], 2).astype(np.float32)
+        k = np.float32(-rng.uniform(0.5, 2.0))
+        p2 = (p1 * k).astype(np.float32)
+        p0 = rng.uniform(-3, 3, 2).astype(np.float32)
+        z = np.float32(-(2.0 + i))
+        for j, q in enumerate((p0, p1, p2)):
+            v[3 * i + j] = (q[0], q[1], z)
+    tris = np.arange(3 * n_tris, dtype=np.uint16).reshape(-1, 3)
+    info = np.zeros(1, dtype=irl.MESH_INFO); info[0] = (0, 0, n_tris, 3 * n_tris)
+    mats = np.zeros(1, dtype=irl.MATERIAL); mats[0]["albedo"] = (.7, .6, .5); mats[0]["ior"] = 1.52
+    mat_ids = np.zeros(1, dtype=np.uint32)
+    g = irl.SceneDesc()
+    g.mesh_info, g.num_meshes = info.ctypes.data, 1
+    g.mesh_tris, g.num_tris = tris.ctypes.data, n_tris
+    g.mesh_verts, g.num_verts = v.ctypes.data, len(v)
+    g.mat_ids, g.num_mat_ids = mat_ids.ctypes.data, 1
+    g.materials, g.num_materials = mats.ctypes.data, 1
+    g.fov_radians = 0.9
+    hs = irl.HostScene.from_arrays(g)
+    hs._keep = [v, tris, info, mats, mat_ids]
+    return hs
+
+
+def test_double_fallback_variant_on_grazing_edge_rays_bit_exact():
+    """Scene option "double_fallback" = the reference built with -DALLOW_DOUBLE_FALLBACK=1 (CMakeLists.txt:13,34-41;
+    src/Mesh.cpp:38-51): edge functions that come out exactly zero in binary32 are recomputed in binary64. Rays through
+    triangle edges, both settings, shadow trace (the caller's rays as given) and path trace: the GPU equals the oracle
+    built the same way bit for bit, and the two settings do differ on these rays."""
+    differing = 0
+    for seed in range(6):
+        s = _grazing_scene(np.random.default_rng(900 + seed), 48)
+        d = s.desc
+        d.set_image(16, 8); d.path_trace = 0
+        rays = np.zeros(128, dtype=irl.TRACE_RESULT)
+        rays["h"]["r"]["direction"]["z"] = -1.0
+        rays["h"]["r"]["tMax"] = np.inf
+        rays["h"]["primID"] = irl.INVALID_PRIM; rays["h"]["geomID"] = irl.INVALID_GEOM
+        # ray 0 is the constructed one; the others leave from origins a few ulp to a few percent away from it
+        rng = np.random.default_rng(seed)
+        rays["h"]["r"]["origin"]["x"][1:] = (rng.normal(size=127) * np.logspace(-7, -2, 127)).astype(np.float32)
+        rays["h"]["r"]["origin"]["y"][1:] = (rng.normal(size=127) * np.logspace(-7, -2, 127)).astype(np.float32)
+        results = {}
+        for df in (0, 1):
+            dev = irl.IpuScene(d).set_option("double_fallback", df)
+            got = rays.copy(); want = rays.copy()
+            dev.run(got, irl.MODE_SHADOW_TRACE)
+            if df:
+                with ol.double_fallback():
+                    ol.shadow_trace(d, want, 4)
+            else:
+                ol.shadow_trace(d, want, 4)
+            assert_streams_identical(got, want, f"grazing rays, double_fallback={df}, seed {seed}")
+            results[df] = got
+            dev.close()
+        differing += int((results[0]["h"]["primID"] != results[1]["h"]["primID"]).sum())
+    assert differing > 0, "the constructed rays never took the binary64 branch to a different verdict"
+    # path trace through the variant's kernels (the phase-scheduled kernel's build with the branch compiled in)
+    s = irl.HostScene.builtin("box"); d = s.desc
+    d.set_image(96, 64); d.samples_per_pixel = 12; d.path_trace = 1
+    want = s.init_ray_stream()
+    with ol.double_fallback():
+        ol.path_trace_pixel_rng(d, want, 16)
+    for kernel in ("1", "0"):
+        dev = irl.IpuScene(d).set_option("double_fallback", 1).set_option("kernel", kernel)
+        got = s.init_ray_stream(); dev.run(got, irl.MODE_PATH_TRACE); dev.close()
+        assert_streams_identical(got, want, f"path trace, double_fallback=1, kernel {kernel}")
+
+
+def test_fast_tier_within_its_stated_tolerance(scenes):
+    """Scene option "fast" = 1, the tolerance tier (never the default, never the headline): box test as FMAs on
+    (plane, 1/d, -o/d) with a conservatively widened far side, triangle test contracted with v_rcp_f32 for 1/det. Same
+    per-pixel RNG streams as the exact tier, so the two renders are compared pixel by pixel. Stated tolerance:
+      * first hits (max path length 1: the hit-t / hit point / normal / id AOVs): the SAME primitive in every pixel, hit
+        distance and hit point within 1e-6 relative, normal identical;
+      * one bounce (max path length 2) at 8 spp: the last sample's record names another primitive in at most 2e-4 of the
+        pixels (measured 7e-5); where it names the same one, the hit distance agrees to 1e-5 of (t + the scene's
+        extent) in at least 99 % of the pixels (a grazing second segment amplifies the first hit's ulps without bound), and
+        there hit point and normal agree to 1e-5 relative;
+      * whole paths (length 10) at 8 spp: another primitive in at most 1 % of the pixels (measured 0.6 %). That figure is the reference algorithm's own knife edge, not the tier's arithmetic: a bounce ray leaves a
+        wall from a point offset by rayEpsilon (Render.hpp:25-33), 1-2 ulp at the box scene's coordinates, and whether it
+        re-hits that wall at t ~ 1e-7..1e-4 is decided by Mesh.cpp:84-101's error bound (t <= deltaT); about 9e-4 of the
+        exact tier's own second and later hits are such self-intersections (checked below), and any change of a last bit
+        flips some of them, after which the path draws different random numbers (about 3 % of the last samples' paths
+        are re-drawn in all);
+      * at 256 spp the rgb sums agree to 2e-3 per channel over the image (the two renders are the same estimator with
+        ~3 % of their paths re-drawn)."""
+    s = scenes["box"]; d = s.desc
+    d.set_image(720, 720); d.samples_per_pixel = 1; d.path_trace = 1; d.max_path_length = 1
+    exact = irl.IpuScene(d); fast = irl.IpuScene(d).set_option("fast", 1)
+    a = s.init_ray_stream(); exact.run(a, irl.MODE_PATH_TRACE)
+    b = s.init_ray_stream(); fast.run(b, irl.MODE_PATH_TRACE)
+    exact.close(); fast.close()
+    assert np.array_equal(a["h"]["primID"], b["h"]["primID"]) and np.array_equal(a["h"]["geomID"], b["h"]["geomID"]) and np.array_equal(a["h"]["flags"], b["h"]["flags"])
+    hitm = a["h"]["primID"] != irl.INVALID_PRIM
+    assert hitm.mean() > 0.6          # (the frame looks into the open box: about 30 % of the primary rays pass beside it)
+    ta, tb = a["h"]["r"]["tMax"][hitm], b["h"]["r"]["tMax"][hitm]
+    assert np.all(np.abs(ta - tb) <= 1e-6 * np.abs(ta)) and np.any(ta != tb), "first-hit distances: within 1e-6, and not the exact tier's bits"
+    for c in "xyz":
+        assert np.all(np.abs(a["h"]["r"]["origin"][c][hitm] - b["h"]["r"]["origin"][c][hitm]) <= 1e-6 * 1500.0)
+        assert np.array_equal(a["h"]["normal"][c], b["h"]["normal"][c])
+    # the knife edge quoted above, in the EXACT tier: self-intersections among its second hits
+    d.max_path_length = 3; d.roulette_start_depth = 100
+    exact = irl.IpuScene(d)
+    a = s.init_ray_stream(); exact.run(a, irl.MODE_PATH_TRACE); exact.close()
+    t3 = a["h"]["r"]["tMax"]; t3 = t3[np.isfinite(t3)]
+    assert 1e-4 < np.mean(t3 < 1e-2) < 5e-3, np.mean(t3 < 1e-2)
+    # one bounce (max path length 2), 8 spp: the literal form of the tolerance
+    d.max_path_length = 2; d.samples_per_pixel = 8
+    exact = irl.IpuScene(d); fast = irl.IpuScene(d).set_option("fast", 1)
+    a = s.init_ray_stream(); exact.run(a, irl.MODE_PATH_TRACE)
+    b = s.init_ray_stream(); fast.run(b, irl.MODE_PATH_TRACE)
+    exact.close(); fast.close()
+    same = (a["h"]["primID"] == b["h"]["primID"]) & (a["h"]["geomID"] == b["h"]["geomID"]) & (a["h"]["flags"] == b["h"]["flags"])
+    assert (~same).mean() <= 2e-4, f"one bounce: hit identity differs in {(~same).mean():.2e} of the pixels"
+    fin = same & np.isfinite(a["h"]["r"]["tMax"]) & np.isfinite(b["h"]["r"]["tMax"])
+    # (the second cast starts from a first-hit point that differs by a few ulp of the scene's coordinates, ~1e-3 units: a
+    # short or grazing second segment carries that as an ABSOLUTE error, hence 1e-5 of (t + the scene's extent))
+    t_a = a["h"]["r"]["tMax"][fin]; dt = np.abs(t_a - b["h"]["r"]["tMax"][fin])
+    within = dt <= 1e-5 * (np.abs(t_a) + 1500.0)
+    assert fin.mean() > 0.2 and np.mean(~within) <= 1e-2, (fin.mean(), np.mean(~within))        # measured 2.6e-3: grazing second segments
+    ok = np.zeros(a.size, bool); ok[np.nonzero(fin)[0][within]] = True
+    for c in "xyz":
+        assert np.mean(np.abs(a["h"]["r"]["origin"][c][ok] - b["h"]["r"]["origin"][c][ok]) <= 1e-5 * 1500.0) >= 0.999, c
+        assert np.mean(np.isclose(a["h"]["normal"][c][ok], b["h"]["normal"][c][ok], rtol=1e-5, atol=1e-5)) >= 0.999, c
+    # whole paths (max path length 10, roulette from depth 3), 8 spp
+    d.max_path_length = 10; d.roulette_start_depth = 3
+    exact = irl.IpuScene(d); fast = irl.IpuScene(d).set_option("fast", 1)
+    a = s.init_ray_stream(); exact.run(a, irl.MODE_PATH_TRACE)
+    b = s.init_ray_stream(); fast.run(b, irl.MODE_PATH_TRACE)
+    exact.close(); fast.close()
+    ol_check = s.init_ray_stream()[::997].copy(); ol.path_trace_pixel_rng(d, ol_check, 16)
+    assert_streams_identical(a[::997].copy(), ol_check, "the exact tier next to the fast one is still the oracle's")
+    same = (a["h"]["primID"] == b["h"]["primID"]) & (a["h"]["geomID"] == b["h"]["geomID"]) & (a["h"]["flags"] == b["h"]["flags"])
+    assert (~same).mean() <= 1e-2, f"hit identity differs in {(~same).mean():.2e} of the pixels"
+    d.set_image(360, 360); d.samples_per_pixel = 256
+    exact = irl.IpuScene(d); fast = irl.IpuScene(d).set_option("fast", 1)
+    a = s.init_ray_stream(); exact.run(a, irl.MODE_PATH_TRACE)
+    b = s.init_ray_stream(); fast.run(b, irl.MODE_PATH_TRACE)
+    ra = np.stack([a["rgb"][k] for k in "xyz"], 1); rb = np.stack([b["rgb"][k] for k in "xyz"], 1)
+    assert np.allclose(ra.sum(0), rb.sum(0), rtol=2e-3), (ra.sum(0), rb.sum(0))
+    exact.close(); fast.close()
+    d.set_image(96, 64); d.samples_per_pixel = 5
