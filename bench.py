@@ -48,12 +48,12 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
-# MI355X_MICROARCH.md: HBM3E 8 TB/s spec; L2 ~34.5 TB/s aggregate; vector L1 (TCP) 64 B/clk/CU; ~2.5 PFLOP/s dense f16 MFMA
+# MI355X_MICROARCH.md: HBM3E 8 TB/s spec; L2 ~34.5 TB/s aggregate; ~2.5 PFLOP/s dense f16 MFMA. (No vector-L1 figure there: K1w's roof is measured, see `roofline`.)
 HBM_PEAK_GBS = 8000.0
 L2_PEAK_GBS = 34500.0
-L1_BYTES_PER_CLK_PER_CU = 64.0
 MFMA_F16_PEAK_TFLOPS = 2500.0
-PMC_SUMMARY = ROOT / "profiles" / "r02_pmc_summary.json"   # rocprofv3 --pmc passes of this same command (tools/prof_r02.sh + tools/collect_profiles.py)
+PMC_SUMMARY = ROOT / "profiles" / "r03_pmc_summary.json"   # rocprofv3 --pmc passes of this same command (tools/prof_r03.sh + tools/collect_profiles.py)
+GATHER_PROBE = ROOT / "profiles" / "r03_gather_probe.json"  # tools/gather_probe.py on the same scene (fallback when the probe cannot run in this process)
 
 
 def image_shape(n_gpus: int, base: int, weak: bool):
@@ -310,7 +310,6 @@ def main():
     props = torch.cuda.get_device_properties(local_rank)
     cus = int(props.multi_processor_count)
     clock_ghz = float(getattr(props, "clock_rate", 2400000)) / 1e6
-    l1_peak_gbs = L1_BYTES_PER_CLK_PER_CU * cus * clock_ghz
 
     out = {
         "metric": "rays/sec (ray casts/s: CompactBvh intersect+occluded calls, whole node), built-in scene 1440x1440 path-trace",
@@ -341,6 +340,14 @@ def main():
     # Algorithmic bytes per cast: 24 B per node visited + the 42-B primitive record per leaf test + one
     # 36-B material; per pixel 84 B in + 84 B out once per frame. Nodes and primitive tests per cast are counted by the
     # instrumented kernel build on the same frame at 64 spp (untimed), which also reports the lanes active per phase.
+    # The roof. The 0.5 MB scene is cache resident (HBM sees 0.1 % of its peak: `hbm` below), so the memory-side roof of
+    # this kernel is the rate at which a CU can serve its walk's dependent 32-byte node gathers. MI355X_MICROARCH.md has
+    # no figure for that (LDS, L2, HBM and MFMA rates only), so it is MEASURED: csrc/probe/gather_probe.hip performs only
+    # the gathers - two global_load_dwordx4 per lane at an index that depends on the node fetched before, a tree-shaped
+    # walk over THIS scene's node array, K1w's launch shape (256-thread workgroups, 5 per CU), as many of a wave's 64
+    # lanes active as K1w's box-test turns have - and its rate (TA busy 0.99: profiles/r03_gather_probe_pmc.txt) is the
+    # peak; `frac` = K1w's gathers per second / the probe's. In this run when the probe library is there, else from
+    # profiles/r03_gather_probe.json.
     roof = {"kernel": "path_trace_wavefront_kernel", "avg_launch_ms": avg_kernel_s * 1e3}
     if not args.no_extras:
         probe_desc = irl.SceneDesc.from_buffer_copy(d)
@@ -358,12 +365,38 @@ def main():
         achieved_gbs = alg_bytes_launch / avg_kernel_s / 1e9
         cyc = ph["cycles"]
         lanes = {k: (ph[k]["lanes"] / (64.0 * ph[k]["iters"]) if ph[k]["iters"] else 0.0) for k in ("node", "leaf", "shade", "gen")}
+        # K1w's gathers: one 32-byte device node per node visited, 48 bytes (1.5 x 32) of primitive record per leaf test
+        gathers_per_cast = nodes_per_cast + 1.5 * leaf_per_cast
+        gathers_per_s = casts_per_launch * gathers_per_cast / avg_kernel_s
+        node_lanes = max(1, min(64, int(round(lanes["node"] * 64))))
+        gather = {"gathers_per_cast": gathers_per_cast, "gathers_per_s": gathers_per_s, "active_lanes": node_lanes,
+                  "unit": "32-byte lane-gathers per second, whole chip"}
+        try:
+            sys.path.insert(0, str(ROOT / "tools"))
+            import gather_probe as gp
+            lib = gp.build()
+            nodes32 = gp.device_nodes(scene)
+            gather["attainable_gathers_per_s"] = gp.measure(lib, nodes32, 0, 1, node_lanes)[1]
+            gather["attainable_uniform_random"] = gp.measure(lib, nodes32, 0, 0, node_lanes)[1]
+            gather["attainable_from_lds"] = gp.measure(lib, nodes32, 1, 1, node_lanes)[1]
+            gather["measured"] = "in this run (ipu_ray_lib_amd/libmi_gather_probe.so)"
+        except Exception as e:      # no probe library and no hipcc here: the committed run of the same probe
+            pj = json.loads(GATHER_PROBE.read_text()) if GATHER_PROBE.exists() else {"rows": []}
+            row = min((r for r in pj["rows"] if r["path"].startswith("L1") and r["walk"] == "tree-shaped" and r["wg_per_cu"] == 5),
+                      key=lambda r: abs(r["active_lanes"] - node_lanes), default=None)
+            if row:
+                gather["attainable_gathers_per_s"] = row["lane_gathers_per_s"]
+                gather["measured"] = f"offline: {GATHER_PROBE.name} @ {pj.get('source_commit')}, {row['active_lanes']} lanes ({type(e).__name__}: probe not runnable here)"
+        att = gather.get("attainable_gathers_per_s")
         roof.update({
-            # The 0.5 MB scene is cache resident: the bytes a cast touches come out of the per-CU vector L1 (TA/TCP path),
-            # so that is the memory-side roof of this kernel; HBM only sees the ray records (`hbm` below).
-            "bound": "l1", "achieved": achieved_gbs, "peak": l1_peak_gbs, "unit": "GB/s", "frac": achieved_gbs / l1_peak_gbs,
-            "peak_source": f"{L1_BYTES_PER_CLK_PER_CU:.0f} B/clk/CU x {cus} CUs x {clock_ghz:.2f} GHz (MI355X_MICROARCH.md)",
-            "l2": {"peak": L2_PEAK_GBS, "frac": achieved_gbs / L2_PEAK_GBS},
+            "bound": "l1", "achieved": achieved_gbs, "unit": "GB/s",
+            "peak": (att * bytes_per_cast / gathers_per_cast / 1e9) if att else None,
+            "frac": (gathers_per_s / att) if att else None,
+            "peak_source": "measured: the node-gather microbenchmark csrc/probe/gather_probe.hip (tools/gather_probe.py) - tree-shaped dependent walk over this "
+                           "scene's node array, two 16-byte loads per lane, K1w's occupancy and lane count - converted to algorithmic bytes with this "
+                           "frame's bytes per gather; MI355X_MICROARCH.md gives no vector-L1 gather rate",
+            "gather_roof": gather,
+            "l2": {"peak": L2_PEAK_GBS, "frac": achieved_gbs / L2_PEAK_GBS, "source": "MI355X_MICROARCH.md (34.5 TB/s aggregate)"},
             "bytes_per_cast": bytes_per_cast, "nodes_per_cast": nodes_per_cast, "leaf_tests_per_cast": leaf_per_cast,
             "lanes_active": dict(lanes, note="instrumented build, same frame at 64 spp: lanes in the phase / 64 per wave turn"),
             "cycle_share": {k: cyc[k] / max(cyc["total"], 1) for k in ("traverse", "shade", "gen")},
@@ -371,13 +404,18 @@ def main():
         traffic = None
         if PMC_SUMMARY.exists():
             # measured offline by rocprofv3 --pmc passes of this same command (separate passes per counter group,
-            # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); only quoted for the profiled workload
+            # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); only quoted for the profiled workload,
+            # every such field marked with the file and the commit it was collected at
             pm = json.loads(PMC_SUMMARY.read_text())
             if pm.get("workload") == [args.scene, width, height, args.spp, world]:
+                mark = f"offline, {PMC_SUMMARY.name} @ {pm.get('source_commit')}"
                 traffic = pm.get("hbm_bytes_per_launch")
                 roof["hbm"] = {"traffic_bytes_per_launch": traffic, "achieved": traffic / avg_kernel_s / 1e9, "peak": HBM_PEAK_GBS,
-                               "frac": traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS, "unit": "GB/s", "measured": "offline, " + PMC_SUMMARY.name}
-                roof["valu"] = dict(pm.get("valu", {}), measured="offline, " + PMC_SUMMARY.name)
+                               "frac": traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS, "unit": "GB/s", "measured": mark}
+                roof["valu"] = dict(pm.get("valu", {}), measured=mark)
+                if pm.get("l1_accesses_per_clk_per_cu") is not None:
+                    roof["l1_accesses_per_clk_per_cu"] = {"k1w": pm["l1_accesses_per_clk_per_cu"], "ta_busy": pm.get("ta_busy"),
+                                                          "probe_at_saturation": pm.get("probe_l1_accesses_per_clk_per_cu"), "measured": mark}
         roof["traffic"] = traffic
     out["roofline"] = roof
 
@@ -405,6 +443,14 @@ def main():
         pcnt = pv.counters()
         out["preview_16spp"] = {"ms_per_frame": ms, "rays_per_s": pcnt["casts"] / 11.0 / (ms * 1e-3), "workload": f"{width}x{height} x 16 spp"}
         pv.close(); del pv_rays
+        # ---------------- the tolerance tier (scene option "fast": FMA box / triangle tests), same frame; never the headline ----------------
+        fd = irl.IpuScene(irl.SceneDesc.from_buffer_copy(d)).set_option("fast", 1)
+        f_rays = to_device(torch, irl, host_rays)
+        ms = time_launches(torch, lambda: fd.run_device(f_rays.data_ptr(), n, irl.MODE_PATH_TRACE, stream.cuda_stream), 2, stream)
+        fcnt = fd.counters()
+        out["fast_tier"] = {"ms_per_frame": ms, "rays_per_s": fcnt["casts"] / 3.0 / (ms * 1e-3), "workload": f"{width}x{height} x {args.spp} spp",
+                            "note": "not bit-exact: results within the tolerance stated in tests/test_gpu_parity.py::test_fast_tier_within_its_stated_tolerance"}
+        fd.close(); del f_rays
 
     rc = 0
     if not args.no_cpu_baseline and world == 1:

@@ -228,7 +228,7 @@ namespace {
 void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
   auto need = [](bool ok, const char* what) { if (!ok) throw ArgError(std::string("mi_scene_create: ") + what); };
   need(d.num_nodes == 0 || d.bvh_nodes, "bvh_nodes is null");
-  need(d.num_nodes < kLeafFlag, "more than 2^31 - 1 BVH nodes");
+  need(d.num_nodes < (kLeafFlag >> 5), "more than 2^26 - 1 BVH nodes");
   need(d.num_geometry == 0 || d.geometry, "geometry is null");
   need(d.num_geometry <= 0xFFFF, "more than 65535 geometries (geomID is 16 bit)");
   need(d.num_mat_ids >= d.num_geometry, "All primitives must be assigned a material.");
@@ -292,8 +292,8 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
     g.maxx = n.min_x + half_bits_to_float(n.dx);                  // CompactBVH2Node.cpp:8-10, one rounded add each
     g.maxy = n.min_y + half_bits_to_float(n.dy);
     g.maxz = n.min_z + half_bits_to_float(n.dz);
-    g.link = skip[i];
-    g.hit = i + 1;                                                 // interior: the first child
+    g.link = skip[i] << 5;                                         // (byte offsets: trace_kernels.hpp GNode)
+    g.hit = (i + 1) << 5;                                          // interior: the first child
     if (n.geom_id != MI_INVALID_GEOM) {
       need(n.geom_id < d.num_geometry, "leaf geomID out of range");
       const mi_geom_ref& r = d.geometry[n.geom_id];
@@ -321,7 +321,7 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
         L.type = LEAF_DISC | ((uint32_t)n.geom_id << 16); L.primID = 0;
       }
       L.matIndex = d.mat_ids[n.geom_id];
-      g.hit = skip[i] | kLeafFlag;                                 // leaf: stop in front of link (= i + 1)
+      g.hit = (skip[i] << 5) | kLeafFlag;                          // leaf: stop in front of link (= i + 1)
       leaves[i] = L;
       isLeafNode[i] = 1;
     }

@@ -27,7 +27,8 @@ namespace mi {
 // a 64-bit register pair feeds the packed subtract/multiply directly.
 struct __attribute__((aligned(16))) GNode {
   float minx, maxx, miny, maxy, minz, maxz;
-  uint32_t link;                                  // where the walk goes on when the box is MISSED: next(i), the node after i's subtree in preorder (numNodes = the walk ends)
+  // Both successors are BYTE offsets into the node array (index << 5), ready to be added to the array's base:
+  uint32_t link;                                  // where the walk goes on when the box is MISSED: next(i), the node after i's subtree in preorder (numNodes << 5 = the walk ends)
   uint32_t hit;                                   // where it goes on when the box is HIT: interior node: i + 1 (its first child); leaf: link | kLeafFlag -
                                                   // "stop: the primitive of the node BEFORE `link` is to be tested" (a leaf's link is i + 1)
 };
@@ -323,7 +324,7 @@ __device__ __forceinline__ bool traverse(const DeviceScene& sc, f3 o, f3 d, floa
       }
     }
     // next node in the reference's visit order
-    i = (boxHit && !isLeaf) ? i + 1 : nd.link;
+    i = (boxHit && !isLeaf) ? i + 1 : (nd.link >> 5);
   }
   return hit.leaf != 0xFFFFFFFFu;
 }

@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES_PER_SIMD) path_trace_pool_ke
         const bool boxHit = !(t0 > t1);
         const bool isLeaf = node_is_leaf(nd);
         pendLeaf = node;                                          // (leaves[] is indexed by node)
-        node = (boxHit && !isLeaf) ? node + 1 : nd.link;          // (a lane that waits for a primitive test already stands at the node behind it)
+        node = (boxHit && !isLeaf) ? node + 1 : (nd.link >> 5);          // (a lane that waits for a primitive test already stands at the node behind it)
         if (boxHit && isLeaf) { ph = PP_LEAF; return false; }
         if (node >= numNodes) { ph = PP_FIN; return false; }
         return true;

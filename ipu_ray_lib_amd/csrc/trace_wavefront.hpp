@@ -103,7 +103,6 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
   }
   extern __shared__ __attribute__((aligned(16))) unsigned char dynLds[];
   load_sin_table(sinTbl);
-  const GNode* ldsNodes = reinterpret_cast<const GNode*>(dynLds);
   if (LDS_NODES) {
     // stage the first ldsNodeCount nodes (preorder prefix) once per workgroup, 16 B per lane per step
     const uint4* src = reinterpret_cast<const uint4*>(sc.nodes);
@@ -116,7 +115,9 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
   const uint32_t fetchChunk = ex.fetchChunk ? ex.fetchChunk : 64u;
   uint32_t chunkNext = 0, chunkEnd = 0;          // wave-uniform: the local range of work indices not handed out yet
   const uint32_t tiledCount = tileStreamW ? (n / (8u * tileStreamW)) * (8u * tileStreamW) : 0u;
-  const uint32_t numNodes = sc.numNodes;
+  // `node` (and the successors stored in a device node) are BYTE offsets into the node array, so a box test's load needs no
+  // shift; numNodes is the array's end in the same unit.
+  const uint32_t numNodes = sc.numNodes << 5;
   const uint32_t spp = ex.sampleCount ? ex.sampleCount : sc.samplesPerPixel;
   const bool segd = ex.segPart != nullptr || slots;          // (pixel, segment) work atoms
   const uint32_t segShift = segment_shift(sc.samplesPerPixel), segMask = (1u << segShift) - 1u;
@@ -243,8 +244,8 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
         {
           GNode nd;
           // (uniform base + 32-bit byte offset: the load takes the scalar-base form, one shift instead of 64-bit address math)
-          if (LDS_NODES && node < ldsNodeCount) nd = ldsNodes[node];
-          else nd = *reinterpret_cast<const GNode*>(reinterpret_cast<const char*>(sc.nodes) + (node << 5));
+          if (LDS_NODES && node < (ldsNodeCount << 5)) nd = *reinterpret_cast<const GNode*>(dynLds + node);
+          else nd = *reinterpret_cast<const GNode*>(reinterpret_cast<const char*>(sc.nodes) + node);
           if (STATS) cs.nodes++;
           // Box test (CompactBVH2Node.cpp:5-22, intersectRaySlab CompactBVH2Node.hpp:14-50).
           // Fast form: with finite origin and finite inverse direction no slab product can be NaN, and for
@@ -284,9 +285,9 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
           const bool boxHit = !(t0 > t1);
           if (SPEC) {
             const bool isLeaf = node_is_leaf(nd);
-            const uint32_t here = node;                            // (leaves[] is indexed by node)
+            const uint32_t here = node >> 5;                       // (leaves[] is indexed by node)
             if (STATS) { if (pend1 != 0xFFFFFFFFu) { cs.nodes--; specNodes++; } }
-            node = (boxHit && !isLeaf) ? node + 1 : nd.link;      // (a lane always stands at the node BEHIND a primitive it waits for; pend1Node likewise)
+            node = (boxHit && !isLeaf) ? node + 32u : nd.link;    // (a lane always stands at the node BEHIND a primitive it waits for; pend1Node likewise)
             if (boxHit && isLeaf) {
               if (pend1 != 0xFFFFFFFFu) { pendLeaf = here; ph = PH_LEAF; return false; }     // a second one: wait
               pend1 = here; pend1Node = node;                                                // the first one: walk on
@@ -391,7 +392,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
           } else
           if (ph == PH_LEAF) {
             if (STATS) cs.leaves++;
-            const uint32_t atLeaf = node - 1u;          // the leaf the lane stopped at (its link is the node after it)
+            const uint32_t atLeaf = (node >> 5) - 1u;   // the leaf the lane stopped at (its link is the node after it)
             const GLeaf L = sc.leaves[atLeaf];
             float t, b0 = 0.f, b1 = 0.f, b2 = 0.f;
             bool cand;
@@ -521,7 +522,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
           sh = make_shear(d, inv);
           if (FAST) { oi = mk(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z)); slabPad = 4.8e-7f * fmaxf(fmaxf(fabsf(oi.x), fabsf(oi.y)), fabsf(oi.z)); }
           hit.t = kInf; hit.leaf = 0xFFFFFFFFu;
-          { uint32_t seen; node = root_start(sc, o, seen); if (STATS) cs.nodes += seen; }
+          { uint32_t seen; node = root_start(sc, o, seen) << 5; if (STATS) cs.nodes += seen; }
           ++casts;
           ph = (numNodes > 0) ? PH_NODE : PH_SHADE;
         }
@@ -575,7 +576,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
         sh = make_shear(d, inv);
         if (FAST) { oi = mk(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z)); slabPad = 4.8e-7f * fmaxf(fmaxf(fabsf(oi.x), fabsf(oi.y)), fabsf(oi.z)); }
         hit.t = kInf; hit.leaf = 0xFFFFFFFFu;
-        { uint32_t seen; node = root_start(sc, o, seen); if (STATS) cs.nodes += seen; }
+        { uint32_t seen; node = root_start(sc, o, seen) << 5; if (STATS) cs.nodes += seen; }
         ++casts;
         ph = (numNodes > 0) ? PH_NODE : PH_SHADE;
         pathStore();

@@ -8,25 +8,34 @@ walk-shaped index sequences, at K1w's occupancy (5 workgroups of 256 threads per
 Prints a table and writes the JSON. Units: lane-gathers (one lane fetching one 32-byte node = two 16-byte loads) per
 shader clock per CU, with the clock the run measured (GRBM-free: kernel time x the device's nominal clock is NOT used;
 the probe reports rates per second and, from --clock-ghz (default: the nominal 2.4), per clock)."""
-import argparse, ctypes as C, json, subprocess, sys
+import argparse, ctypes as C, json, sys
 from pathlib import Path
 import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 import ipu_ray_lib_amd as irl
 
-SRC = ROOT / "ipu_ray_lib_amd" / "csrc" / "probe" / "gather_probe.hip"
-LIB = ROOT / "build" / "probe" / "libgather_probe.so"
+LIB = ROOT / "ipu_ray_lib_amd" / "libmi_gather_probe.so"       # built by __graft_entry__.build_probe() from csrc/probe/gather_probe.hip
 
 
 def build():
-    LIB.parent.mkdir(parents=True, exist_ok=True)
-    if not LIB.exists() or LIB.stat().st_mtime < SRC.stat().st_mtime:
-        subprocess.run(["hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-shared", "-o", str(LIB), str(SRC)], check=True)
+    """The probe library (built in-tree next to the product library so that it travels to the GPU box; it is NOT part of
+    the product: nothing under ipu_ray_lib_amd/*.py loads it)."""
+    import __graft_entry__ as ge
+    ge.build_probe()
     lib = C.CDLL(str(LIB))
     lib.gp_run.restype = C.c_double
     lib.gp_run.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]
     return lib
+
+
+def measure(lib, nodes, path, walk, lanes, wg=5, steps=20000, reps=3, lds_nodes=512):
+    """One configuration: (average launch ms, lane-gathers per second chip-wide)."""
+    blocks = C.c_uint32()
+    ms = lib.gp_run(nodes.ctypes.data, nodes.size, path, walk, steps, lanes, lds_nodes if path else 1, wg, reps, C.byref(blocks))
+    if ms <= 0:
+        raise RuntimeError("gather probe failed")
+    return ms, blocks.value * 4 * lanes * steps / (ms * 1e-3)
 
 
 def device_nodes(scene):
@@ -72,13 +81,8 @@ def main():
                     for lanes in (16, 35, 64):
                         cfgs.append((path, walk, lanes, wg, 512))
     for path, walk, lanes, wg, ldsn in cfgs:
-        blocks = C.c_uint32()
         ldsn_eff = ldsn if path else 0
-        ms = lib.gp_run(nodes.ctypes.data, nodes.size, path, walk, args.steps, lanes, max(ldsn_eff, 1), wg, args.reps, C.byref(blocks))
-        if ms <= 0:
-            raise SystemExit("gp_run failed")
-        gathers = blocks.value * 4 * lanes * args.steps           # waves x active lanes x steps
-        per_s = gathers / (ms * 1e-3)
+        ms, per_s = measure(lib, nodes, path, walk, lanes, wg, args.steps, args.reps, ldsn)
         per_clk_cu = per_s / 256 / (args.clock_ghz * 1e9)
         rows.append({"path": paths[path], "walk": "tree-shaped" if walk else "uniform", "active_lanes": lanes, "wg_per_cu": wg, "lds_nodes": ldsn_eff,
                      "ms": ms, "lane_gathers_per_s": per_s, "lane_gathers_per_clk_per_cu": per_clk_cu,
@@ -86,7 +90,13 @@ def main():
         print(f"wg/CU {wg}  {rows[-1]['walk']:<11} {paths[path]:<12} lanes {lanes:>2}: {ms:8.3f} ms  {per_s:.3e} lane-gathers/s  "
               f"{per_clk_cu:.3f} /clk/CU  (wave steps {per_clk_cu / lanes * 1e3:.2f} per 1000 clk per CU)", flush=True)
     if args.out:
-        Path(args.out).write_text(json.dumps({"scene": args.scene, "nodes": int(nodes.size), "steps": args.steps, "clock_ghz_assumed": args.clock_ghz, "rows": rows}, indent=1))
+        import subprocess
+        try:
+            commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip() or None
+        except OSError:
+            commit = None
+        Path(args.out).write_text(json.dumps({"scene": args.scene, "nodes": int(nodes.size), "steps": args.steps, "clock_ghz_assumed": args.clock_ghz,
+                                              "source_commit": commit, "rows": rows}, indent=1))
 
 
 if __name__ == "__main__":
