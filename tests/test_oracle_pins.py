@@ -398,3 +398,43 @@ def test_bvh_queries_against_brute_force(o, name):
             assert got.hit == 0
         else:
             assert got.hit == 1 and got.t == np.float32(best_t)
+
+
+def test_double_fallback_switch_restates_mesh_cpp_38_51(o):
+    """ALLOW_DOUBLE_FALLBACK=1 (CMakeLists.txt:13,34-41; src/Mesh.cpp:38-51) as a switch of the oracle: when a binary32
+    edge function is exactly zero, all three are recomputed from binary64 products and differences. Checked against a
+    numpy restatement of those lines on rays that pass through a triangle edge up to rounding (p2.xy = fl(k * p1.xy),
+    ray (0,0,0) -> (0,0,-1): no permutation, no shear, the edge functions are those of the vertex coordinates)."""
+    import oracle_lib as ol
+    rng = np.random.default_rng(5)
+    ray = Ray(v3((0, 0, 0)), 0.0, v3((0, 0, -1)), float("inf")); sh = Shear(); o.o_ray_shear(C.byref(ray), C.byref(sh))
+    assert (sh.ix, sh.iy, sh.iz) == (0, 1, 2) and sh.sx == 0 and sh.sy == 0
+    took_branch = changed = 0
+    for _ in range(400):
+        p1 = (rng.uniform(0.5, 2.0, 2) * rng.choice([-1, 1], 2)).astype(np.float32)
+        p2 = (p1 * np.float32(-rng.uniform(0.5, 2.0))).astype(np.float32)
+        p0 = rng.uniform(-3, 3, 2).astype(np.float32)
+        P = [(float(q[0]), float(q[1]), -4.0) for q in (p0, p1, p2)]
+        bary = (f32 * 3)()
+        t0 = o.o_intersect_triangle(v3(P[0]), v3(P[1]), v3(P[2]), C.byref(sh), float("inf"), bary)
+        with ol.double_fallback():
+            t1 = o.o_intersect_triangle(v3(P[0]), v3(P[1]), v3(P[2]), C.byref(sh), float("inf"), bary)
+        assert o.o_get_double_fallback() == 0
+        # numpy: binary32 edge functions, then the binary64 branch
+        x = np.array([q[0] for q in P], np.float32); y = np.array([q[1] for q in P], np.float32)
+        e = [np.float32(np.float32(x[1] * y[2]) - np.float32(y[1] * x[2])), np.float32(np.float32(x[2] * y[0]) - np.float32(y[2] * x[0])),
+             np.float32(np.float32(x[0] * y[1]) - np.float32(y[0] * x[1]))]
+        if any(v == 0 for v in e):
+            took_branch += 1
+            X, Y = x.astype(np.float64), y.astype(np.float64)
+            e64 = [np.float32(Y[2] * X[1] - X[2] * Y[1]), np.float32(Y[0] * X[2] - X[0] * Y[2]), np.float32(Y[1] * X[0] - X[1] * Y[0])]
+            miss32 = (min(e) < 0) and (max(e) > 0)
+            miss64 = (min(e64) < 0) and (max(e64) > 0)
+            assert (t0 == 0.0) == bool(miss32 or sum(e) == 0) or t0 == 0.0      # (a hit may still be rejected further down)
+            if miss64:
+                assert t1 == 0.0
+            if (t0 == 0.0) != (t1 == 0.0):
+                changed += 1
+        else:
+            assert t0 == t1
+    assert took_branch > 100 and changed > 0
