@@ -84,7 +84,14 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES_PER_SIMD) path_trace_pool_ke
 
   // ---- rings ----
   // number of entries on a ring as this wave sees it now (reserved entries included)
-  auto ringCount = [&](uint32_t r) -> uint32_t { return vctl[4 + r] - vctl[r]; };
+  // (head first, then tail, each read exactly once: the tail can only have grown in between, so the difference never wraps
+  // downwards; other waves may push and claim between the two reads, hence the clamp to the ring's capacity)
+  auto ringCount = [&](uint32_t r) -> uint32_t {
+    const uint32_t head = vctl[r];
+    const uint32_t tail = vctl[4 + r];
+    const uint32_t c = tail - head;
+    return c > (uint32_t)PWG ? (uint32_t)PWG : c;
+  };
   // push the slots of the lanes with p: everything the slot needs (LDS words, scratch) was written before
   auto ringPush = [&](uint32_t r, bool p, uint32_t s) {
     const unsigned long long m = __ballot(p);
@@ -95,7 +102,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES_PER_SIMD) path_trace_pool_ke
     base = uni(__shfl(base, (int)((uint32_t)__ffsll((long long)m) - 1u)));
     if (p) {
       volatile uint16_t* e = ringEnt + r * RCAP + ((base + lanesBelow(m)) & RM);
-      while (*e != kRingEmpty) {}                  // (the entry's previous occupant has been claimed but not read yet: never seen in practice)
+      while (*e != kRingEmpty) __builtin_amdgcn_s_sleep(1);      // (the entry's previous occupant has been claimed but not read yet: never seen in practice; its reader needs the LDS port this poll would occupy)
       *e = (uint16_t)s;
     }
   };
@@ -115,7 +122,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES_PER_SIMD) path_trace_pool_ke
   auto ringTake = [&](uint32_t r, uint32_t idx) -> uint32_t {
     volatile uint16_t* e = ringEnt + r * RCAP + (idx & RM);
     uint32_t s;
-    do { s = *e; } while (s == kRingEmpty);        // reserved by a pushing wave, not written yet
+    for (;;) { s = *e; if (s != kRingEmpty) break; __builtin_amdgcn_s_sleep(1); }        // reserved by a pushing wave, not written yet: back off while it writes
     *e = (uint16_t)kRingEmpty;
     return s;
   };
