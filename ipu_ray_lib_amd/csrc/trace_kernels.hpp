@@ -41,9 +41,10 @@ static_assert(sizeof(GNode) == 32, "GNode must stay 32 bytes");
 
 enum : uint32_t { LEAF_TRI = 0, LEAF_SPHERE = 1, LEAF_DISC = 2 };
 
-struct __attribute__((aligned(16))) GLeaf {       // 64 B pre-resolved primitive (the primitive test reads the first 48); leaves[i] belongs to leaf NODE i
+struct __attribute__((aligned(16))) GLeaf {       // 64 B pre-resolved primitive (the primitive test reads the first 40); leaves[i] belongs to leaf NODE i
+  uint32_t type;     // LEAF_* in bits 0..15, geomID in bits 16..31. FIRST, so that it arrives with the first 16-byte load of
+                     // the record (the test branches on it) and a triangle is three loads (16 + 16 + 8 bytes), not four
   float f[9];        // tri: p0,p1,p2 | sphere: cx,cy,cz,radius,radius2 | disc: nx,ny,nz,cx,cy,cz,r2
-  uint32_t type;     // LEAF_* in bits 0..15, geomID in bits 16..31
   uint32_t primID;   // value reported in the hit record
   uint32_t triBase;  // tri: index of the triangle's first u16 in meshTris (for vertex normals)
   float n[3];        // tri: the face normal normalise(cross(p1-p0, p2-p0)) (Mesh.hpp:112-114), evaluated once at

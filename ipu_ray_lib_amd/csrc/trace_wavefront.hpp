@@ -393,7 +393,8 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
           if (ph == PH_LEAF) {
             if (STATS) cs.leaves++;
             const uint32_t atLeaf = (node >> 5) - 1u;   // the leaf the lane stopped at (its link is the node after it)
-            const GLeaf L = sc.leaves[atLeaf];
+            // (uniform base + 32-bit byte offset, as for the nodes: a 64-byte record per 32-byte node)
+            const GLeaf L = *reinterpret_cast<const GLeaf*>(reinterpret_cast<const char*>(sc.leaves) + ((node - 32u) << 1));
             float t, b0 = 0.f, b1 = 0.f, b2 = 0.f;
             bool cand;
             const uint32_t kind = leaf_kind(L);
