@@ -115,6 +115,20 @@ __device__ __forceinline__ Shear make_shear(f3 d, f3 inv) {
   return s;
 }
 
+// The tolerance tier's cast set-up: 1/d by v_rcp_f32 (1 ulp) and the shear as products with it instead of two more
+// correctly rounded divisions (five division sequences of ~10 instructions per cast become three instructions).
+__device__ __forceinline__ f3 fast_inverse(f3 d) { return mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)); }
+__device__ __forceinline__ Shear make_shear_fast(f3 d, f3 inv) {
+  Shear s;
+  s.kz = min_index(d);
+  uint32_t kx = s.kz + 1; if (kx == 3) kx = 0;
+  uint32_t ky = kx + 1; if (ky == 3) ky = 0;
+  s.sz = comp(inv, s.kz);
+  s.sx = -comp(d, kx) * s.sz;
+  s.sy = -comp(d, ky) * s.sz;
+  return s;
+}
+
 __device__ __forceinline__ f3 permute_kz(f3 p, uint32_t kz) {
   // (kx,ky,kz) is the cyclic rotation that puts component kz last. Written as selects: as three early returns
   // hipcc built divergent regions (exec-mask juggling, ~50 scalar instructions in dependent chains per

@@ -518,9 +518,12 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
         } else {
           // next bounce: offsetRay + cast set-up (codelets :207-211)
           o = offset_origin(o, d, nrm);
-          inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
-          exactSlab = !(fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf && fabsf(o.x) < kInf && fabsf(o.y) < kInf && fabsf(o.z) < kInf);
-          sh = make_shear(d, inv);
+          if (FAST) { inv = fast_inverse(d); sh = make_shear_fast(d, inv); }
+          else {
+            inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+            exactSlab = !(fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf && fabsf(o.x) < kInf && fabsf(o.y) < kInf && fabsf(o.z) < kInf);
+            sh = make_shear(d, inv);
+          }
           if (FAST) { oi = mk(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z)); slabPad = 4.8e-7f * fmaxf(fmaxf(fabsf(oi.x), fabsf(oi.y)), fabsf(oi.z)); }
           hit.t = kInf; hit.leaf = 0xFFFFFFFFu;
           { uint32_t seen; node = root_start(sc, o, seen) << 5; if (STATS) cs.nodes += seen; }
@@ -572,9 +575,12 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
         color = mk(0.f, 0.f, 0.f);
         bounce = 0;
         o = offset_origin(o, d, nrm);
-        inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
-        exactSlab = !(fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf && fabsf(o.x) < kInf && fabsf(o.y) < kInf && fabsf(o.z) < kInf);
-        sh = make_shear(d, inv);
+        if (FAST) { inv = fast_inverse(d); sh = make_shear_fast(d, inv); }
+        else {
+          inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+          exactSlab = !(fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf && fabsf(o.x) < kInf && fabsf(o.y) < kInf && fabsf(o.z) < kInf);
+          sh = make_shear(d, inv);
+        }
         if (FAST) { oi = mk(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z)); slabPad = 4.8e-7f * fmaxf(fmaxf(fabsf(oi.x), fabsf(oi.y)), fabsf(oi.z)); }
         hit.t = kInf; hit.leaf = 0xFFFFFFFFu;
         { uint32_t seen; node = root_start(sc, o, seen) << 5; if (STATS) cs.nodes += seen; }
