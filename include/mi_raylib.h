@@ -218,7 +218,14 @@ int mi_scene_set_ray_batch(mi_scene* scene, size_t rays_per_batch);
  *   "nif_spl"       0..128          NIF samples per launch (0 = default)
  *   "nif_shape"     w6 | t6 | t4    workgroup shape of the NIF MLP kernel
  *   "pin"           0 | 1           page-lock the caller's stream for the duration of mi_render
- * None of them changes a result bit. The keys "fast" and "double_fallback" (below) select arithmetic variants and DO. */
+ * None of them changes a result bit. Two further keys select ARITHMETIC:
+ *   "double_fallback" 0 | 1         the reference built with -DALLOW_DOUBLE_FALLBACK=1 (CMakeLists.txt:13,34-41; src/Mesh.cpp:38-51):
+ *                                   edge functions that are exactly zero in binary32 are recomputed in binary64. Results are those
+ *                                   of the reference's CPU path built the same way, bit for bit (default 0 = the reference default)
+ *   "fast"            0 | 1         tolerance tier for plain path-trace renders of the default kernel: box test as FMAs, triangle
+ *                                   test contracted, v_rcp_f32 in the cast set-up. NOT bit-exact: first hits name the same primitive
+ *                                   with distance / point within 1e-6; see tests/test_gpu_parity.py (test_fast_tier_...) for the
+ *                                   stated tolerance. Never the default. */
 int mi_scene_set_option(mi_scene* scene, const char* key, const char* value);
 
 /* The NIF environment evaluated stand-alone on device arrays: for i<n, bgr[i*3..] =
