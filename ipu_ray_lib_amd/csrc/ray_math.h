@@ -36,13 +36,17 @@ MI_HD float comp(f3 a, uint32_t i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z);
 
 // geometry.hpp:115-125. Named maxi/maxc upstream; they select the SMALLEST component and
 // every caller depends on that.
+// Written as two compare / select pairs: "x < y ? (x < z ? x : z) : (y < z ? y : z)" is "m = x < y ? x : y; m < z ? m : z" -
+// the SAME comparisons on the same operands in either branch (NaN behaviour included), but hipcc evaluates all three
+// compares of the nested form (the triangle test takes four of these per primitive).
 MI_HD uint32_t min_index(f3 v) {
-  if (v.x < v.y) return v.x < v.z ? 0u : 2u;
-  return v.y < v.z ? 1u : 2u;
+  const bool xy = v.x < v.y;
+  const float m = xy ? v.x : v.y;
+  return (m < v.z) ? (xy ? 0u : 1u) : 2u;
 }
 MI_HD float min_comp(f3 v) {
-  if (v.x < v.y) return v.x < v.z ? v.x : v.z;
-  return v.y < v.z ? v.y : v.z;
+  const float m = (v.x < v.y) ? v.x : v.y;
+  return (m < v.z) ? m : v.z;
 }
 
 // precision_utils.hpp:18-25
