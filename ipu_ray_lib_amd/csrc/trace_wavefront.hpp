@@ -409,7 +409,10 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
               t = intersect_disc(L, o, d);
               cand = true;
             }
-            if (cand && t > 0.f && t < hit.t) { hit.t = t; hit.leaf = atLeaf; hit.b0 = b0; hit.b1 = b1; hit.b2 = b2; }
+            // (five selects on one mask: as an if-block hipcc copies the five values out, branches, and copies them back)
+            const bool closer = cand & (t > 0.f) & (t < hit.t);
+            hit.t = closer ? t : hit.t; hit.leaf = closer ? atLeaf : hit.leaf;
+            hit.b0 = closer ? b0 : hit.b0; hit.b1 = closer ? b1 : hit.b1; hit.b2 = closer ? b2 : hit.b2;
             ph = (node >= numNodes) ? PH_SHADE : PH_NODE;
           }
           // every lane that waited for a primitive test is walking again: the next vote would pick NODE anyway,
