@@ -7,7 +7,7 @@ the script form runs for a time budget. Every case draws
 a scene (built-in scenes, or a random triangle soup with nasty triangles: zero-area, needle, axis-aligned and
 duplicated/coplanar ones, with or without vertex normals, plus spheres and discs), render parameters (image size
 incl. ragged widths, crop window, 1..900 samples so that both segment lengths and their boundaries are crossed, seed, jitter, path length,
-roulette depth), a render mode and a kernel variant, renders it with the library and with the oracle, and compares
+roulette depth), a render mode, a kernel variant and (one case in five) the ALLOW_DOUBLE_FALLBACK=1 build on both sides, renders it with the library and with the oracle, and compares
 every byte of every TraceResult. The first mismatch stops the run with the case's parameters (exit code 1).
 
 With a fourth argument `nif` the cases are renders with a NIF environment (random small MLP, random samples per
@@ -203,9 +203,10 @@ def campaign(budget=240.0, seed=1, scale=1, max_cases=None):
         kernel = str(rng.choice(["0", "1", "1", "3", "3", "2"]))
         waves = str(rng.choice(["4", "5"]))
         batch = int(rng.integers(1, 4000)) if rng.random() < 0.25 else 0
+        df = int(rng.random() < 0.2)          # the reference's ALLOW_DOUBLE_FALLBACK=1 build, on both sides (Mesh.cpp:38-51)
         desc = (f"case {case} (seed {seed}): {what} {w}x{h} crop={crop} spp={spp} rngseed={d.rng_seed} aa={d.anti_alias_scale} "
-                f"len={d.max_path_length} roulette={d.roulette_start_depth} mode={mode} kernel={kernel} waves={waves} batch={batch}")
-        dev = irl.IpuScene(d).set_option("kernel", kernel).set_option("waves", waves).set_option("spec", int(rng.integers(0, 2)))
+                f"len={d.max_path_length} roulette={d.roulette_start_depth} mode={mode} kernel={kernel} waves={waves} batch={batch} double_fallback={df}")
+        dev = irl.IpuScene(d).set_option("kernel", kernel).set_option("waves", waves).set_option("spec", int(rng.integers(0, 2))).set_option("double_fallback", df)
         got = s.init_ray_stream()
         if rng.random() < 0.3:
             for k in "xyz":
@@ -213,10 +214,14 @@ def campaign(budget=240.0, seed=1, scale=1, max_cases=None):
         want = got.copy()
         dev.setRayBatch(batch)
         dev.run(got, mode)
-        if mode == irl.MODE_PATH_TRACE:
-            ol.path_trace_pixel_rng(d, want, threads)
-        else:
-            ol.shadow_trace(d, want, threads)
+        ol.lib().o_set_double_fallback(df)
+        try:
+            if mode == irl.MODE_PATH_TRACE:
+                ol.path_trace_pixel_rng(d, want, threads)
+            else:
+                ol.shadow_trace(d, want, threads)
+        finally:
+            ol.lib().o_set_double_fallback(0)
         dev.close()
         bad = differing(got, want)
         if bad.size:
