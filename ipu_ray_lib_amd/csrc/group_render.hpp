@@ -285,7 +285,18 @@ void groupRender(mi_group& G, int mode, mi_trace_result* rays, size_t n, mi_ray_
   // traced, gathered and brought home on its own; the callback of a batch runs while the next one is in flight.
   const size_t batch = (G.rayBatch && G.rayBatch < n) ? G.rayBatch : n;
   const size_t numBatches = (n + batch - 1) / batch;
-  groupEnsureBuffers(G, groupPlan(G, batch));
+  {
+    // buffers for every batch of this render: all batches but the last have `batch` rays; the last one is shorter and -
+    // when only one of the two sizes is made of whole window rows - may be dealt in bands of another size, so a replica
+    // can get MORE rays of the short batch than of a full one
+    mi_group::Plan need = groupPlan(G, batch);
+    const size_t lastSize = n - (numBatches - 1) * batch;
+    if (lastSize != batch) {
+      const mi_group::Plan last = groupPlan(G, lastSize);
+      for (size_t r = 0; r < need.count.size(); ++r) need.count[r] = std::max(need.count[r], last.count[r]);
+    }
+    groupEnsureBuffers(G, need);
+  }
   G.resident.n = 0;                    // the shares are about to be overwritten
   PinGuard pin(G, rays, n * kRec);
   groupResetLog(G);

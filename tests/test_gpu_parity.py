@@ -987,6 +987,26 @@ def test_replica_group_renders_the_single_scene_frame(scenes, replicas, transpor
     d.path_trace = 1; d.set_image(96, 64); d.samples_per_pixel = 5
 
 
+def test_replica_group_short_last_batch_dealt_in_other_bands(scenes):
+    """A 100 x 90 window in batches of 4 050 rays: the two full batches are not made of whole rows (one 4 050-ray band
+    each: everything goes to replica 0), the last batch is 900 rays = nine whole rows and is dealt in 8-row bands, so
+    replica 1 gets 100 rays of it although it had none of the full batches. Every share buffer must hold the largest
+    share of ANY batch."""
+    s = scenes["box"]; d = s.desc
+    d.set_image(100, 90); d.samples_per_pixel = 5; d.path_trace = 1
+    want = s.init_ray_stream(); ol.path_trace_pixel_rng(d, want, 16)
+    for transport in (irl.TRANSPORT_RCCL, irl.TRANSPORT_COPY):
+        grp = irl.IpuGroup(d, [0, 0, 0], transport)
+        grp.setRayBatch(4050)
+        got = s.init_ray_stream(); seen = []
+        grp.run(got, irl.MODE_PATH_TRACE, callback=lambda idx, first, cnt: seen.append((idx, first, cnt)))
+        assert_streams_identical(got, want, "short last batch in other bands")
+        assert seen == [(0, 0, 4050), (1, 4050, 4050), (2, 8100, 900)]
+        assert grp.last_transfer()["bands"] == 1 + 1 + 2
+        grp.close()
+    d.set_image(96, 64)
+
+
 def test_config4_frame_2880_x_1000spp_through_eight_replicas_and_rccl(scenes):
     """BASELINE config 4 at its real size, as far as one GPU allows: the 2880x2880 x 1000 spp box frame through
     mi_group_* with EIGHT replicas (all on device 0), RCCL transport - 360 bands of 8 rows dealt round-robin, one
