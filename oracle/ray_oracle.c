@@ -7,6 +7,7 @@
  * binary32 operation with no fused multiply-add, so results are reproducible bit for bit
  * on any x86-64 host and by the -ffp-contract=off HIP build.
  */
+#define _GNU_SOURCE          /* sched_getaffinity / CPU_COUNT */
 #include "ray_oracle.h"
 
 #include <math.h>
@@ -14,6 +15,9 @@
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+#endif
+#if defined(__linux__)
+#include <sched.h>
 #endif
 
 /* ------------------------------------------------------------------------- */
@@ -894,7 +898,35 @@ static inline float round_through_half(float f) { return o_half_to_float(o_float
 /* NifModel.cpp:186-246, 300-327. Features [sin(u*2^j) | sin(v*2^j) | cos(u*2^j) | cos(v*2^j)],
  * u,v normalised to 2*(uv-1). Dense(+bias)(+ReLU) chain; when a layer's row count differs from
  * the activation width the features are appended to the activations first. */
-void o_nif_infer(const onif* nif, const float* u, const float* v, size_t n, float* bgr) {
+/* threads for a team nobody sized: the cores this process may run on (sched_getaffinity), not the machine's */
+static int oracle_default_threads(void) {
+  int n = 0;
+#if defined(__linux__)
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+#endif
+  if (n < 1) n = 1;
+  if (n > 64) n = 64;
+  return n;
+}
+
+/* the weights as the arithmetic sees them (rounded through binary16 once when the model is an fp16 one) */
+static float** nif_prepare_weights(const onif* nif) {
+  float** W = (float**)malloc(sizeof(float*) * nif->numLayers);
+  for (uint32_t l = 0; l < nif->numLayers; ++l) {
+    size_t cnt = (size_t)nif->rows[l] * nif->cols[l];
+    W[l] = (float*)malloc(sizeof(float) * cnt);
+    for (size_t k = 0; k < cnt; ++k) W[l][k] = nif->halfWeightsActs ? round_through_half(nif->kernels[l][k]) : nif->kernels[l][k];
+  }
+  return W;
+}
+static void nif_free_weights(const onif* nif, float** W) {
+  for (uint32_t l = 0; l < nif->numLayers; ++l) free(W[l]);
+  free(W);
+}
+
+/* rows with only[i] == 0 are skipped (their bgr is left alone); only == NULL: every row */
+static void nif_infer_with(const onif* nif, float** W, const float* u, const float* v, size_t n, float* bgr, const uint8_t* only, int numThreads) {
   const uint32_t E = nif->embeddingDimension;
   const uint32_t F = 4 * E;
   uint32_t maxW = F;
@@ -902,20 +934,17 @@ void o_nif_infer(const onif* nif, const float* u, const float* v, size_t n, floa
     if (nif->rows[l] > maxW) maxW = nif->rows[l];
     if (nif->cols[l] > maxW) maxW = nif->cols[l];
   }
-  /* optionally pre-round the weights once */
-  float** W = (float**)malloc(sizeof(float*) * nif->numLayers);
-  for (uint32_t l = 0; l < nif->numLayers; ++l) {
-    size_t cnt = (size_t)nif->rows[l] * nif->cols[l];
-    W[l] = (float*)malloc(sizeof(float) * cnt);
-    for (size_t k = 0; k < cnt; ++k) W[l][k] = nif->halfWeightsActs ? round_through_half(nif->kernels[l][k]) : nif->kernels[l][k];
-  }
-#pragma omp parallel
+  /* (never more threads than the caller asked for: on a box that grants this process 16 of its 100+ cores an unbounded
+   * team oversubscribes them and spends the time spinning at its barriers) */
+  if (numThreads < 1) numThreads = oracle_default_threads();
+#pragma omp parallel num_threads(numThreads)
   {
     float* feat = (float*)malloc(sizeof(float) * F);
     float* x = (float*)malloc(sizeof(float) * (maxW + F));
     float* y = (float*)malloc(sizeof(float) * (maxW + F));
-#pragma omp for schedule(static)
+#pragma omp for schedule(dynamic, 4)
     for (long long i = 0; i < (long long)n; ++i) {
+      if (only && !only[i]) continue;
       const float un = (u[i] - 1.f) * 2.f, vn = (v[i] - 1.f) * 2.f;      /* NifModel.cpp:203-205 */
       for (uint32_t j = 0; j < E; ++j) {
         const float coeff = (float)(1u << j);                           /* makeCoefficients, NifModel.cpp:467-473 */
@@ -949,8 +978,12 @@ void o_nif_infer(const onif* nif, const float* u, const float* v, size_t n, floa
     }
     free(feat); free(x); free(y);
   }
-  for (uint32_t l = 0; l < nif->numLayers; ++l) free(W[l]);
-  free(W);
+}
+
+void o_nif_infer(const onif* nif, const float* u, const float* v, size_t n, float* bgr) {
+  float** W = nif_prepare_weights(nif);
+  nif_infer_with(nif, W, u, v, n, bgr, NULL, 0);
+  nif_free_weights(nif, W);
 }
 
 /* PostProcessEscapedRays, codelets/TraceCodelets.cpp:361-382 */
@@ -978,6 +1011,10 @@ void o_path_trace_nif_pixel_rng(const oscene* sc, const onif* nif, float azimuth
   ovec3* total = (ovec3*)malloc(sizeof(ovec3) * (n ? n : 1));
   ostats tot = {0, 0, 0, 0};
   if (numThreads < 1) numThreads = 1;
+  /* (the weights are prepared once for the render, and the MLP runs for the rays that escaped only: PostProcessEscapedRays
+   * reads no other ray's result - the same values as evaluating every ray every sample, in a fraction of the time) */
+  float** W = nif_prepare_weights(nif);
+  uint8_t* escaped = (uint8_t*)malloc(n ? n : 1);
   for (uint32_t smp = 0; smp < sc->samplesPerPixel; ++smp) {
     if (smp % segLen == 0) {
       const uint32_t segment = smp / segLen;
@@ -1000,9 +1037,11 @@ void o_path_trace_nif_pixel_rng(const oscene* sc, const onif* nif, float azimuth
       { tot.casts += loc.casts; tot.nodesVisited += loc.nodesVisited; tot.leafTests += loc.leafTests; tot.paths += loc.paths; }
     }
     o_escaped_uv(rays, n, azimuthRotation, u, v);
-    o_nif_infer(nif, u, v, n, bgr);
+    for (size_t i = 0; i < n; ++i) escaped[i] = (rays[i].h.flags & O_FLAG_ESCAPED) ? 1 : 0;
+    nif_infer_with(nif, W, u, v, n, bgr, escaped, numThreads);
     o_apply_env(rays, n, bgr);
   }
+  nif_free_weights(nif, W); free(escaped);
   if (sc->samplesPerPixel > segLen)
     for (size_t i = 0; i < n; ++i) rays[i].rgb = vadd(total[i], rays[i].rgb);
   if (st) { st->casts += tot.casts; st->nodesVisited += tot.nodesVisited; st->leafTests += tot.leafTests; st->paths += tot.paths; }

@@ -796,7 +796,7 @@ def test_config5_monkey_nif_1440_x_256spp_against_oracle():
 
 def test_config5_monkey_nif_1440_x_4000spp_against_oracle():
     """BASELINE config 5 at its real size on one GPU: monkey bust + NIF environment, 1440x1440 x 4000 spp (63 segments
-    per pixel, 32 launches of 128 samples' slots). Every 6421st pixel (323 pixels) against the oracle's NIF render at
+    per pixel, 32 launches of 128 samples' slots). Every 3001st pixel (691 pixels) against the oracle's NIF render at
     4000 spp: hit records bit exact; rgb sums within the MLP tolerance of test_nif_mlp_against_oracle (2 % relative on a
     decoded radiance; a pixel's sum averages 4000 samples: 1 % + a small absolute term for 99 % of the pixels, 5 %
     for all)."""
@@ -809,12 +809,12 @@ def test_config5_monkey_nif_1440_x_4000spp_against_oracle():
     dev.setNif(ks, bs, relu, 12, 3.4299468994140625, mean, True)
     got = s.init_ray_stream()
     dev.run(got, irl.MODE_PATH_TRACE)
-    want = s.init_ray_stream()[::6421].copy()
-    assert want.size >= 300
+    want = s.init_ray_stream()[::3001].copy()
+    assert want.size >= 600
     nif, keep = ol.make_nif(ks, bs, relu, 12, 3.4299468994140625, mean, True, half_features=True, half_weights_acts=True)
     st = ol.Stats()
     ol.lib().o_path_trace_nif_pixel_rng(C.byref(d), C.byref(nif), 0.0, want.ctypes.data, want.size, 16, C.byref(st))
-    sub = got[::6421].copy()
+    sub = got[::3001].copy()
     assert rows_differing(np.ascontiguousarray(sub["h"]), np.ascontiguousarray(want["h"])).size == 0, "config 5: hit records must be bit exact"
     g = np.stack([sub["rgb"][k] for k in "xyz"], 1); w = np.stack([want["rgb"][k] for k in "xyz"], 1)
     assert w.max() > 0
