@@ -210,7 +210,7 @@ int mi_scene_set_ray_batch(mi_scene* scene, size_t rays_per_batch);
  *   "waves"         4 | 5           waves per SIMD the default kernel is built for (5: the 96-VGPR build)
  *   "spec"          0 | 1           kernel 1: lanes walk on past ONE pending primitive test
  *   "full_stats"    0 | 1           instrumented kernels: node / leaf-test counters, phase occupancy
- *   "tune"          "leafAt,shadeAt,genAt[,burst,keep8,dbl,maxExtra(<=5),leafThenNode,prio,leafP]"   scheduling weights of kernel 1
+ *   "tune"          "leafAt,shadeAt,genAt[,burst,keep8,dbl,maxExtra(<=7),leafThenNode,prio,leafP]"   scheduling weights of kernel 1
  *   "pool_waves"    4 | 8 | 16      kernel 3: waves per workgroup
  *   "pool_tune"     "leafAt,burst,retireAt,refillMin,shadeW,genW[,dbl,maxExtra,leafThenNode,prio]"
  *   "tiles"         0 | 1           walk row-structured streams in 8x8 pixel tiles

@@ -134,9 +134,9 @@ struct SceneOptions {
       return true;
     }
     if (key == "tune") {      // leafAt,shadeAt,genAt[,burst,keep8,dbl,maxExtra,leafThenNode,prio,leafP]
-      unsigned a, b, c, dd = 48, k8 = 3, db = 4, mx = 5, ln = 1, pr = 1, lp = 40;
+      unsigned a, b, c, dd = 48, k8 = 3, db = 4, mx = 6, ln = 1, pr = 1, lp = 40;
       if (sscanf(v, "%u,%u,%u,%u,%u,%u,%u,%u,%u,%u", &a, &b, &c, &dd, &k8, &db, &mx, &ln, &pr, &lp) < 3) return false;
-      if (mx > 5) return false;          // the spelled-out run of box tests has six
+      if (mx > 7) return false;          // the spelled-out run of box tests has eight
       tune = {a, b, c, dd, k8, db ? db : 65, mx, ln, pr, lp ? lp : 1};
       return true;
     }

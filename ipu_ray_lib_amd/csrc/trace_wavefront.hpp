@@ -27,7 +27,7 @@ namespace mi {
 enum : uint32_t { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_GEN = 3, PH_FETCH = 4, PH_DONE = 5 };
 
 // Scheduling weights (quarter units, NODE/TRAVERSE weigh 4) and traversal-burst limits; the defaults
-// {8, 16, 24, 48, 3} (dbl 4) are the measured optimum on the box scene (+-1 % plateau):
+// {8, 16, 24, 48, 3} (dbl 4, maxExtra 6) are the measured optimum over the box and the Collada scene (+-1 % plateau):
 //   leafAt   inside a traversal burst, LEAF runs when cL*leafAt > cN*4
 //   shadeAt, genAt   top-level vote: SHADE/GEN run when their weighted population exceeds (cN+cL)*4
 //   burst    at most this many NODE/LEAF steps before the wave re-votes
@@ -37,7 +37,7 @@ enum : uint32_t { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_GEN = 3, PH_FETCH =
 //   prio     1: waves run their traversal turns at s_setprio 1 (short dependent steps win VALU arbitration over
 //            another wave's long SHADE/GEN blocks: +1 %), 0: no priorities
 //   leafP    (SPEC build) a LEAF turn also runs once this many lanes hold a pending primitive test
-struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, dbl = 4, maxExtra = 5, leafThenNode = 1, prio = 1, leafP = 40;
+struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, dbl = 4, maxExtra = 6, leafThenNode = 1, prio = 1, leafP = 40;
   bool operator==(const WaveTune& o) const { return leafAt == o.leafAt && shadeAt == o.shadeAt && genAt == o.genAt && burst == o.burst && keep8 == o.keep8 && dbl == o.dbl && maxExtra == o.maxExtra && leafThenNode == o.leafThenNode && prio == o.prio && leafP == o.leafP; } };
 
 // Per-launch extras for renders with the NIF environment. The reference traces ONE sample, evaluates the
@@ -81,7 +81,7 @@ struct WaveExtras {
 // from ex.slotColor. FIXED_TUNE: the scheduling weights are the compile-time defaults (kDefaultTune) instead of the
 // `tune` argument. The two default-path instantiations (<.., 0, true> and <.., 1, true>) carry neither the other mode's
 // code nor the ten weights in scalar registers: no scalar spills (33 before), -2.5 % frame time.
-constexpr WaveTune kDefaultTune = {8, 16, 24, 48, 3, 4, 5, 1, 1, 40};
+constexpr WaveTune kDefaultTune = {8, 16, 24, 48, 3, 4, 6, 1, 1, 40};      // re-swept on the round-3 kernel on two scenes (profiles/r03_kernel_ab.txt): a cheaper box test favours one more of them per vote
 // DF: the reference's ALLOW_DOUBLE_FALLBACK=1 build of the triangle test (trace_kernels.hpp). FAST: the tolerance tier
 // (scene option "fast"): the box test as three pairs of FMAs on (plane, 1/d, -o/d), the triangle test contracted, no
 // literal NaN-exact fallback - results within a stated tolerance of the exact tier's, not bit-identical.
@@ -338,7 +338,11 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
               if (extra >= 2 && go) { go = nodeBody();
                 if (extra >= 3 && go) { go = nodeBody();
                   if (extra >= 4 && go) { go = nodeBody();
-                    if (extra >= 5 && go) (void)nodeBody();
+                    if (extra >= 5 && go) { go = nodeBody();
+                      if (extra >= 6 && go) { go = nodeBody();
+                        if (extra >= 7 && go) (void)nodeBody();
+                      }
+                    }
                   }
                 }
               }
