@@ -268,10 +268,11 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
           }
           float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
           // FAST: fma(plane, 1/d, -o/d) carries an ABSOLUTE error of about eps * |o/d| (the two terms cancel), far more than
-          // the eps * |t| of the exact tier's (plane - o) * (1/d) and more than the 1 + 2 gamma(3) scale covers: 0.6 % of the
-          // box scene's pixels lost a hit to a falsely missed box. The far side is therefore widened by 8 eps * max |o/d|
-          // (slabPad, per cast) - inside the instruction that applies the scale, so the test stays as cheap and errs on
-          // the side of visiting.
+          // the eps * |t| of the exact tier's (plane - o) * (1/d) and more than the 1 + 2 gamma(3) scale covers, so a thin box
+          // far from the origin could be missed falsely. The far side is therefore widened by 8 eps * max |o/d| (slabPad, per
+          // cast) - inside the instruction that applies the scale, so the test stays as cheap and errs on the side of
+          // visiting. (On the box scene the pad changes nothing measurable: the tier's differences from the exact one come
+          // from the reference's own knife-edge self-intersections)
           float t1 = FAST ? fminf(__builtin_fmaf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)), kSlabScale, slabPad), hit.t)
                           : fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * kSlabScale, hit.t);
           if constexpr (decltype(exactTag)::value) {
