@@ -1,7 +1,7 @@
 // ray_shard.hpp — how a ray stream is dealt to the replicas of a multi-GPU render, and how the frame is put
 // together again. Header-only, host and device: the C ABI of libmi_scene_host.so (mi_shard_*, used by
 // the Python ranks of bench.py through ipu_ray_lib_amd/sharding.py), the single-process renderer mi_group_render in
-// libmi_raylib.so and its de-interleave kernel all share these few functions, so there is one definition of who
+// libmi_raylib.so (whose strided share copies follow this dealing) all share these few functions, so there is one definition of who
 // renders what.
 //
 // Reference: the replicas of an IpuScene pull disjoint ray batches round-robin from one stream
