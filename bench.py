@@ -208,6 +208,8 @@ def main():
     ap.add_argument("--weak", action="store_true", help="N>1: N x size^2 pixels instead of config 4's fixed (2 size)^2 frame")
     ap.add_argument("--devices", default="", help="N>1, single-process group path: comma list of HIP ordinals, one per replica (default 0..N-1; "
                                                   "ordinals may repeat - '0,0' rehearses the two-GPU path on a one-GPU box)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend of the ranks launch (nccl = RCCL; gloo with the ranks "
+                                                                              "sharing the visible GPUs rehearses the ranks path on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (parity spot check and CPU baseline)")
     ap.add_argument("--no-extras", action="store_true", help="skip the instrumented probe, the NIF kernel and the 16-spp frame (profiling runs)")
     args = ap.parse_args()
@@ -233,21 +235,27 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it either as a plain process (single-process "
                          f"group path) or under torch.distributed.run with --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; with --backend gloo (a rehearsal) the ranks may outnumber the visible GPUs and share them
+    dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
         dist.barrier()
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"       # where the collectives' tensors live
 
     width, height = image_shape(world, args.size, args.weak)
     scene = irl.HostScene.builtin(args.scene)
     d = scene.desc
     d.set_image(width, height)
     d.samples_per_pixel = args.spp
-    d.device = local_rank
+    d.device = dev_index
     dev = irl.IpuScene(d)
 
     from ipu_ray_lib_amd import sharding
@@ -261,7 +269,7 @@ def main():
         # the ONE collective of a frame: every rank's rgb tiles to rank 0 over RCCL/xGMI
         if dist is not None:
             rgb = d_rays.view(torch.float32).view(n, 21)[:, 0:3].contiguous()
-            return sharding.gather_frame(dist, rgb, width, height)
+            return sharding.gather_frame(dist, rgb if coll_dev == "cuda" else rgb.cpu(), width, height)
         return None
 
     def frame():
@@ -290,7 +298,7 @@ def main():
     counters = dev.counters()
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
 
-    tot = torch.tensor([elapsed, float(counters["casts"]), float(counters["paths"])], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([elapsed, float(counters["casts"]), float(counters["paths"])], dtype=torch.float64, device=coll_dev)
     if dist is not None:
         tmax = tot.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -307,7 +315,7 @@ def main():
     casts_per_launch = counters["casts"] / max(args.steps, 1)
     paths_per_launch = counters["paths"] / max(args.steps, 1)
     avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) * 1e-3 if kernel_ms else float("nan")
-    props = torch.cuda.get_device_properties(local_rank)
+    props = torch.cuda.get_device_properties(dev_index)
     cus = int(props.multi_processor_count)
     clock_ghz = float(getattr(props, "clock_rate", 2400000)) / 1e6
 
@@ -327,14 +335,14 @@ def main():
         "config": {"workload": f"built-in scene '{args.scene}', path-trace {width}x{height} x {args.spp} spp, max path length 10, "
                                f"roulette depth 3, AA 0.25, seed 1442 (BASELINE config {'2' if world == 1 else '4' if not args.weak else '2, weak-scaled frame'}), "
                                f"{n} pixels on rank 0",
-                   "parallelism": f"ray tiles x{world}" + (" + 1 RCCL gather/frame" if world > 1 else "")},
+                   "parallelism": f"ray tiles x{world}" + ((" + 1 RCCL gather/frame" if args.backend == "nccl" else " + 1 gloo gather/frame (rehearsal)") if world > 1 else "")},
         "paths_per_s": total_paths / elapsed,
         "ms_per_frame": elapsed / max(args.steps, 1) * 1e3,
         "casts_per_path": total_casts / max(total_paths, 1.0),
         "launch": "ranks" if world > 1 else "single",
     }
     if world > 1:
-        out["one_gpu_same_frame_ms"] = one_gpu_same_frame_ms(torch, irl, d, width, height, local_rank)
+        out["one_gpu_same_frame_ms"] = one_gpu_same_frame_ms(torch, irl, d, width, height, dev_index)
 
     # ---------------- roofline of the dominant kernel (the path-trace launch) ----------------
     # Algorithmic bytes per cast: 24 B per node visited + the 42-B primitive record per leaf test + one
