@@ -114,7 +114,8 @@ def host_lib() -> C.CDLL:
     """libmi_scene_host.so — CPU-only scene plumbing."""
     global _host
     if _host is None:
-        lib = _load(PKG_DIR / "libmi_scene_host.so")
+        # (MI_SCENE_HOST_LIB: another build of the same library, e.g. the AddressSanitizer / UBSan build of tools/sanitize_host.sh)
+        lib = _load(Path(os.environ["MI_SCENE_HOST_LIB"]) if os.environ.get("MI_SCENE_HOST_LIB") else PKG_DIR / "libmi_scene_host.so")
         lib.mi_host_last_error.restype = C.c_char_p
         lib.mi_host_scene_builtin.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
         lib.mi_host_scene_import.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
