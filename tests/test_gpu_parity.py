@@ -827,7 +827,7 @@ def test_config5_monkey_nif_1440_x_4000spp_against_oracle():
 def test_gpu_image_against_the_literal_renderCPU_statistically(scenes):
     """Tier 2 on the GPU: the image the HIP path renders (per-pixel streams) against the oracle's literal restatement
     of renderCPU (trace.cpp:190-268: ONE shared generator consumed sequentially, libstdc++ normal_distribution
-    jitter) at 64 and 256 spp. Different random numbers, same estimator - the reference's own acceptance method
+    jitter) at 64 and 256 spp (120 x 120) and at the headline's 1000 spp (64 x 64). Different random numbers, same estimator - the reference's own acceptance method
     (notebook cells 18-19): channel means agree within the Monte-Carlo error, the cross-scheme MSE equals the MSE
     between two GPU renders with different seeds, and falls like 1/spp."""
     s = scenes["box"]; d = s.desc
@@ -852,6 +852,20 @@ def test_gpu_image_against_the_literal_renderCPU_statistically(scenes):
         assert 0.5 < cross / same < 2.0, (spp, cross, same)
         mse[spp] = cross
     assert 2.0 < mse[64] / mse[256] < 8.0, mse
+    # the headline's sample count (1000 spp) on a 64 x 64 frame: 4.1 M samples, about the 256-spp frame's statistics
+    d.set_image(64, 64); d.samples_per_pixel = 1000
+    imgs = []
+    for seed in (1442, 99):
+        d.rng_seed = seed
+        dev = irl.IpuScene(d)
+        r = s.init_ray_stream(); dev.run(r, irl.MODE_PATH_TRACE); dev.close()
+        imgs.append(np.stack([r["rgb"][k] for k in "xyz"], 1) / 1000)
+    d.rng_seed = 1442
+    ref = s.init_ray_stream(); ol.path_trace_shared_rng(d, ref)
+    ref = np.stack([ref["rgb"][k] for k in "xyz"], 1) / 1000
+    assert np.allclose(imgs[0].mean(0), ref.mean(0), rtol=0.035), (imgs[0].mean(0), ref.mean(0))
+    cross = np.mean((imgs[0] - ref) ** 2); same = np.mean((imgs[0] - imgs[1]) ** 2)
+    assert 0.5 < cross / same < 2.0, (cross, same)
     d.set_image(96, 64); d.samples_per_pixel = 5; d.rng_seed = 1442
 
 
