@@ -177,6 +177,11 @@ int mi_get_phase_stats(mi_scene* scene, uint64_t stats[12]);
 /* Scheduler bookkeeping of the path-pool kernel (kernel 3, instrumented build only): {loop iterations, refill turns,
  * lanes refilled, idle iterations, lost ring claims, traversal bursts, lanes walking at burst start, cycles in refill}. */
 int mi_get_pool_stats(mi_scene* scene, uint64_t stats[8]);
+/* Diagnostics of NIF renders (only filled while the scene option "nif_timing" is 1): HIP events bracket every launch of
+ * the MLP kernel on the render's stream. out[0] = milliseconds spent in MLP launches since the last call, out[1] = number
+ * of launches. Synchronises the device and clears the record. tools/bench_config5.py reports the MLP's share of a frame
+ * from it. No reference counterpart. */
+int mi_get_nif_timing(mi_scene* scene, double out[2]);
 
 /* Replaces: IpuScene::loadNifModel (src/IpuScene.cpp:174-187) with the weights handed over as
  * arrays (the file side — nif_metadata.txt + Keras-H5 — is mi_host_nif_load in mi_scene_host.h).
@@ -218,6 +223,7 @@ int mi_scene_set_ray_batch(mi_scene* scene, size_t rays_per_batch);
  *   "nif_spl"       0..128          NIF samples per launch (0 = default)
  *   "nif_shape"     w6 | t6 | t4    workgroup shape of the NIF MLP kernel
  *   "pin"           0 | 1           page-lock the caller's stream for the duration of mi_render
+ *   "nif_timing"    0 | 1           bracket every MLP launch of a NIF render with HIP events (mi_get_nif_timing)
  * None of them changes a result bit. Two further keys select ARITHMETIC:
  *   "double_fallback" 0 | 1         the reference built with -DALLOW_DOUBLE_FALLBACK=1 (CMakeLists.txt:13,34-41; src/Mesh.cpp:38-51):
  *                                   edge functions that are exactly zero in binary32 are recomputed in binary64. Results are those

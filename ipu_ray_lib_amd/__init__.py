@@ -201,6 +201,7 @@ def device_lib() -> C.CDLL:
         lib.mi_group_reset_counters.argtypes = [C.c_void_p]
         lib.mi_get_pool_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         lib.mi_scene_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        lib.mi_get_nif_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         _device = lib
     return _device
 
@@ -466,6 +467,12 @@ class IpuScene:
         _check_dev(self._lib.mi_get_pool_stats(self._h, c))
         return dict(zip(("loops", "refill_turns", "refill_lanes", "idle", "lost_claims", "bursts", "burst_lanes", "refill_cycles"), [int(x) for x in c]))
 
+    def nif_timing(self) -> dict:
+        """Milliseconds in MLP launches (and their number) since the last call; needs set_option("nif_timing", 1)."""
+        c = (C.c_double * 2)()
+        _check_dev(self._lib.mi_get_nif_timing(self._h, c))
+        return {"mlp_ms": float(c[0]), "launches": int(c[1])}
+
     def reset_counters(self):
         _check_dev(self._lib.mi_reset_counters(self._h))
 
@@ -513,6 +520,24 @@ class IpuGroup:
 
     def setRayBatch(self, rays_per_batch: int):
         _check_dev(self._lib.mi_group_set_ray_batch(self._h, int(rays_per_batch)))
+
+    # The NIF model and its settings go to EVERY replica, as the reference streams the weights to every replica of the
+    # replicated graph (src/IpuScene.cpp:535) - what mi::IpuScene::configure does in the C++ host (csrc/host/IpuScene.hpp).
+    def setNif(self, kernels, biases, relu, embedding_dimension, max_value, mean, log_tonemap=True):
+        for sc in self.scenes():
+            sc.setNif(kernels, biases, relu, embedding_dimension, max_value, mean, log_tonemap)
+
+    def loadNifModel(self, asset_path) -> bool:
+        return all(sc.loadNifModel(asset_path) for sc in self.scenes())
+
+    def setHdriRotation(self, degrees: float):
+        for sc in self.scenes():
+            sc.setHdriRotation(degrees)
+
+    def set_option(self, key: str, value) -> "IpuGroup":
+        for sc in self.scenes():
+            sc.set_option(key, value)
+        return self
 
     def run(self, rays: np.ndarray, mode: int | None = None, callback=None) -> np.ndarray:
         assert rays.dtype == TRACE_RESULT and rays.flags["C_CONTIGUOUS"]

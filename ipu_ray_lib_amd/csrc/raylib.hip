@@ -89,6 +89,7 @@ struct SceneOptions {
   uint32_t nifSamplesPerLaunch = 0;               // MI_RAYLIB_NIF_SPL / "nif_spl": 0 = default (128, memory permitting)
   bool pin = true;                 // MI_RAYLIB_PIN / "pin": page-lock the caller's stream for the duration of mi_render
   uint32_t nifShape = 0;           // MI_RAYLIB_NIF_SHAPE / "nif_shape": 0 = w6 (default), 1 = t6, 2 = t4
+  bool nifTiming = false;          // "nif_timing": HIP events round every MLP launch of a NIF render (mi_get_nif_timing)
   // the two options that select ARITHMETIC (every other option leaves every result bit alone):
   bool doubleFallback = false;     // "double_fallback": the reference's ALLOW_DOUBLE_FALLBACK=1 build (CMakeLists.txt:13,34-41; Mesh.cpp:38-51), bit-exact to the oracle in that mode
   bool fast = false;               // "fast": the tolerance tier (FMA box / triangle tests; plain path-trace renders of the default kernel only)
@@ -126,6 +127,7 @@ struct SceneOptions {
     if (key == "seg_budget_kb") { if (!number(v, 1, ~0ull >> 12, q)) return false; segBudgetKb = (size_t)q; return true; }
     if (key == "nif_spl") { if (!number(v, 0, 128, q)) return false; nifSamplesPerLaunch = (uint32_t)q; return true; }
     if (key == "pin") return flag01(v, pin);
+    if (key == "nif_timing") return flag01(v, nifTiming);
     if (key == "double_fallback") return flag01(v, doubleFallback);
     if (key == "fast") return flag01(v, fast);
     if (key == "nif_shape") {
@@ -192,6 +194,7 @@ struct mi_scene {
   float* d_segTotal = nullptr;                                // sample-at-a-time NIF renders: sum of the finished segments, [n][3]
   uint32_t scratchSamples = 0;                                // samples per launch the slot buffers are sized for
   uint32_t scratchAsked = 0;                                  // the MI_RAYLIB_NIF_SPL value they were sized under (0 = default)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> nifTimes;    // option "nif_timing": events round the MLP launches since the last mi_get_nif_timing
 
   ~mi_scene() {
     (void)hipSetDevice(device);
@@ -206,6 +209,7 @@ struct mi_scene {
     for (LaunchSlot& l : slots) { if (l.d_workCounter) (void)hipFree(l.d_workCounter); if (l.d_segPart) (void)hipFree(l.d_segPart); if (l.d_poolScratch) (void)hipFree(l.d_poolScratch); }
     for (int i = 0; i < 2; ++i) { if (d_batch[i]) (void)hipFree(d_batch[i]); if (pipeStream[i]) (void)hipStreamDestroy(pipeStream[i]); }
     if (nifDone) (void)hipEventDestroy(nifDone);
+    for (auto& e : nifTimes) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     nif.release();
   }
   template <class T> T* keep(T* p) { if (p) allocations.push_back((void*)p); return p; }
@@ -564,7 +568,10 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
           ex.index = S.nif.d_index; ex.count = S.nif.d_count; ex.azimuthRotation = radians;
           if (S.opt.fullStats) launchWavefront<true>(S, d_rays, cnt, stream, ex);
           else launchWavefront<false>(S, d_rays, cnt, stream, ex);
+          std::pair<hipEvent_t, hipEvent_t> tm{nullptr, nullptr};
+          if (S.opt.nifTiming) { HIP_CHECK(hipEventCreate(&tm.first)); HIP_CHECK(hipEventCreate(&tm.second)); S.nifTimes.push_back(tm); HIP_CHECK(hipEventRecord(tm.first, stream)); }
           nif_launch_mlp(S.nif, S.d_u, S.d_v, S.nif.d_index, S.nif.d_count, cnt * sc, S.d_bgr, nullptr, stream, true, S.opt.nifShape);
+          if (tm.second) HIP_CHECK(hipEventRecord(tm.second, stream));
           hipLaunchKernelGGL(nif_accumulate_kernel, grid, block, 0, stream, d_rays, cnt, sc, segShift, ex.segBase, S.d_slotColor, S.d_slotTp, S.d_u, S.d_bgr);
         }
       } else {
@@ -751,6 +758,21 @@ int mi_get_pool_stats(mi_scene* scene, uint64_t stats[8]) {
     unsigned long long h[32];
     HIP_CHECK(hipMemcpy(h, scene->d_counters, sizeof h, hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; ++i) stats[i] = h[16 + i];
+  });
+}
+
+int mi_get_nif_timing(mi_scene* scene, double out[2]) {
+  if (!scene || !out) { g_err = "mi_get_nif_timing: null argument"; return MI_ERR_INVALID_ARG; }
+  return guarded([&] {
+    HIP_CHECK(hipSetDevice(scene->device));
+    HIP_CHECK(hipDeviceSynchronize());
+    out[0] = 0.0; out[1] = (double)scene->nifTimes.size();
+    for (auto& e : scene->nifTimes) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) out[0] += ms;
+      (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
+    }
+    scene->nifTimes.clear();
   });
 }
 

@@ -141,3 +141,30 @@ def test_cli_replicas_give_the_byte_identical_exr(tmp_path):
     if n_dev >= 2:
         many, log = _render_exr(tmp_path, "many", "--gpus", str(n_dev))
         assert many == one and f"{n_dev - 1} RCCL send/recv pairs" in log, log
+
+
+@pytest.mark.gpu
+def test_cli_replicas_with_nif_give_the_byte_identical_exr(tmp_path):
+    """`trace --replicas 2 --nif-hdri <assets.extra>`: mi::IpuScene::configure sets the NIF model on EVERY replica of the
+    group (the reference streams the weights to every replica, src/IpuScene.cpp:535), each replica runs the trace -> uv ->
+    MLP -> env-add loop on its bands, one RCCL group call gathers them: the EXR must equal, byte for byte, the one the
+    single-scene render writes (a ray's MLP result does not depend on which rays share its tile)."""
+    golden = ROOT / "tests" / "golden" / "nif_tiny"
+    if not (irl.PKG_DIR / "libmi_nif_h5.so").exists():
+        pytest.skip("HDF5 plugin not built")
+
+    def render(tag, *extra):
+        prefix = tmp_path / tag
+        r = subprocess.run([str(TRACE), "--scene", "spheres", "-w", "200", "-h", "144", "--samples", "12", "--nif-hdri", str(golden),
+                            "--hdri-rotation", "30", "-o", str(prefix), *extra], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert "Loaded NIF model 'nif_tiny'" in r.stderr
+        return Path(str(prefix) + "_rgb_gpu.exr").read_bytes(), r.stderr
+
+    one, _ = render("one")
+    two, log = render("two", "--replicas", "2", "--gather", "rccl")
+    assert two == one and "1 RCCL send/recv pairs" in log, log
+    three, log = render("three", "--replicas", "3", "--gather", "copy", "--ipu-ray-callback")
+    assert three == one and "peer copies" in log, log
+    img = read_exr_bgr(tmp_path / "two_rgb_gpu.exr")
+    assert img.sum() > 0          # the environment is the only light in this scene

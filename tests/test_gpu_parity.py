@@ -1061,6 +1061,95 @@ def test_replica_group_on_every_visible_gpu(scenes):
     d.set_image(96, 64); d.samples_per_pixel = 5
 
 
+# ------------------------------------------------------------------------------------------------------
+# BASELINE config 5 in its SHARDED form: the NIF environment through scene replicas (the reference streams the
+# NIF weights to every replica and runs trace -> uv -> MLP -> env add inside the replicated program,
+# src/IpuScene.cpp:535, 571-583; replicas chosen at trace.cpp:297-309)
+# ------------------------------------------------------------------------------------------------------
+_NIF_MEAN = np.array([-2.3514461517333984, -2.2660605907440186, -1.9648972749710083], np.float32) - np.float32(1e-8)
+_NIF_MAX = 3.4299468994140625
+
+
+def _config5_against_oracle(s, got, stride, ks, bs, relu, spp, q, qtol, maxtol, what):
+    d = s.desc
+    want = s.init_ray_stream()[::stride].copy()
+    nif, keep = ol.make_nif(ks, bs, relu, 12, _NIF_MAX, _NIF_MEAN, True, half_features=True, half_weights_acts=True)
+    st = ol.Stats()
+    ol.lib().o_path_trace_nif_pixel_rng(C.byref(d), C.byref(nif), 0.0, want.ctypes.data, want.size, 16, C.byref(st))
+    sub = got[::stride].copy()
+    assert rows_differing(np.ascontiguousarray(sub["h"]), np.ascontiguousarray(want["h"])).size == 0, f"{what}: hit records must be bit exact"
+    g = np.stack([sub["rgb"][k] for k in "xyz"], 1); w = np.stack([want["rgb"][k] for k in "xyz"], 1)
+    assert w.max() > 0
+    err = np.abs(g - w) / (np.abs(w) + 0.05 * spp)
+    assert np.quantile(err, q) < qtol and err.max() < maxtol, (what, np.quantile(err, q), err.max())
+
+
+@pytest.mark.parametrize("spp", [256, 4000])
+def test_config5_sharded_nif_through_eight_replicas_and_rccl(spp):
+    """BASELINE config 5's sharded form, as far as one GPU allows: monkey bust + NIF environment, 1440x1440, through
+    mi_group_* with EIGHT replicas (all on device 0) and RCCL transport, the NIF model set on every mi_group_scene.
+    Every replica runs its own {trace slots; MLP over its compacted escaped rays; accumulate} loop on its share (per-
+    replica slot scratch, its own nifDone chain), then one group call of 7 send/recv pairs gathers the shares.
+    At 256 spp the gathered frame must equal the SINGLE-scene GPU render byte for byte: a ray's MLP column depends only
+    on that ray's inputs (each MFMA column is one ray; k-order and tile shape do not depend on which rays share the
+    tile), so dealing the rays differently may not change a bit. At both sample counts a pixel subsample goes through
+    the oracle's NIF render (hit records bit exact, rgb within the MLP tolerance of
+    test_config5_monkey_nif_1440_x_256spp_against_oracle / ..._4000spp_...)."""
+    rng = np.random.default_rng(8)
+    ks, bs, relu = _nif_weights(rng)
+    s = irl.HostScene.builtin("monkey"); d = s.desc
+    d.set_image(1440, 1440); d.samples_per_pixel = spp; d.path_trace = 1
+    grp = irl.IpuGroup(d, [0] * 8, irl.TRANSPORT_RCCL)
+    grp.setNif(ks, bs, relu, 12, _NIF_MAX, _NIF_MEAN, True)
+    got = s.init_ray_stream()
+    grp.run(got, irl.MODE_PATH_TRACE)
+    moved = grp.last_transfer()
+    assert (moved["rccl_messages"], moved["peer_copies"], moved["bands"]) == (7, 0, 180)
+    assert moved["upload_copies"] == 8 and moved["download_copies"] == 8
+    assert grp.counters()["paths"] == 1440 * 1440 * spp
+    grp.close()
+    if spp == 256:
+        one = irl.IpuScene(d)
+        one.setNif(ks, bs, relu, 12, _NIF_MAX, _NIF_MEAN, True)
+        single = s.init_ray_stream()
+        one.run(single, irl.MODE_PATH_TRACE)
+        one.close()
+        assert_streams_identical(got, single, "config 5 through 8 replicas + RCCL against the single-scene GPU render")
+        assert (got["h"]["flags"] & irl.FLAG_ESCAPED).mean() > 0.2
+        _config5_against_oracle(s, got, 2053, ks, bs, relu, spp, 0.995, 0.01, 0.1, "config 5 sharded, 256 spp")
+    else:
+        _config5_against_oracle(s, got, 3001, ks, bs, relu, spp, 0.99, 0.01, 0.05, "config 5 sharded, 4000 spp")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rank_streams_with_nif_render_like_the_whole_frame(world):
+    """Config 5's decomposition in the ranks launch (one process per GPU, sharding.py): each rank's stream (8-row bands,
+    round-robin; ragged for world = 3) rendered separately WITH the NIF environment - its own slots, compaction, MLP
+    launches and accumulate pass over a stream that is not the whole window - and scattered back equals the whole-frame
+    NIF render byte for byte, including the rgb sums the MLP contributed to."""
+    from ipu_ray_lib_amd import sharding
+    rng = np.random.default_rng(8)
+    ks, bs, relu = _nif_weights(rng)
+    s = irl.HostScene.builtin("monkey"); d = s.desc
+    w, h = 256, 200
+    d.set_image(w, h); d.samples_per_pixel = 70; d.path_trace = 1      # 70 spp: segments of 8, the last one short
+    dev = irl.IpuScene(d)
+    dev.setNif(ks, bs, relu, 12, _NIF_MAX, _NIF_MEAN, True)
+    dev.setHdriRotation(77.0)
+    whole = s.init_ray_stream()
+    dev.run(whole, irl.MODE_PATH_TRACE)
+    assert (whole["h"]["flags"] & irl.FLAG_ESCAPED).mean() > 0.2 and whole["rgb"]["x"].max() > 0
+    frame = np.zeros_like(whole)
+    fresh = s.init_ray_stream()
+    for rank in range(world):
+        rows, cols = sharding.rank_pixels(w, h, rank, world)
+        part = fresh[rows * w + cols].copy()
+        dev.run(part, irl.MODE_PATH_TRACE)
+        frame[rows * w + cols] = part
+    assert_streams_identical(frame, whole, f"NIF render, {world} rank streams")
+    dev.close()
+
+
 def test_nif_escaped_ray_with_nan_environment_coordinate(scenes):
     """A case the long fuzz campaign found (tests/fuzz_parity.py nif, seed 20261005, case 8486; parameters and the
     weight generator's state in tests/golden/nif_nan_coordinate_case.json): one escaped ray's direction has |y|
