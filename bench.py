@@ -13,13 +13,16 @@ kernel over a ray stream that is already resident in HBM.
           inside the timed region. Two launch forms, the same dealing (csrc/ray_shard.hpp) behind both:
             "launch": "ranks"  under torch.distributed.run (WORLD_SIZE = N): one process per GPU, rank 0 gathers the
                                rgb tiles with one dist.gather;
-            "launch": "group"  started as a plain `python bench.py --gpus N` (WORLD_SIZE unset): ONE process drives
+            "launch": "group"  started as a plain `python bench.py --gpus N --launch group`: ONE process drives
                                the N devices through the C++ host path mi_group_* (what `trace --gpus N` runs): shares
                                resident on their devices, timed region = K x mi_group_trace (trace + one RCCL
                                send/recv group call of the full TraceResults to device 0).
           The frame is the same for N = 2, 4, 8 ("scaling": "strong"); --weak renders N x 1440^2 pixels instead.
           For N > 1 the line also carries "one_gpu_same_frame_ms": the same frame on one device alone, measured in
-          the same run, as the anchor of the scaling curve.
+          the same run, as the anchor of the scaling curve; "rccl_ranks" (distinct devices in the communicator, with the
+          backend's name) and per-step "gather_ms", so that a record says by itself how many devices it ran on. The group
+          launch has not yet run on two physical devices: it is only taken when asked for by name, and `--devices` with a
+          repeated ordinal (replicas sharing a GPU) needs `--rehearsal`.
 
 After the timed loop (outside it) rank 0 at N = 1
   * copies ~2 000 pixels of the LAST timed frame back and compares all 84 bytes of each with the CPU oracle run over
@@ -136,6 +139,9 @@ def bench_group(args, torch, irl):
     devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(n_gpus))
     if len(devices) != n_gpus:
         raise SystemExit(f"bench.py: --devices names {len(devices)} replicas, --gpus {n_gpus}")
+    if len(set(devices)) != len(devices) and not args.rehearsal:
+        raise SystemExit("bench.py: --devices repeats an ordinal: replicas that share a GPU rehearse the plumbing, they do not measure scaling. "
+                         "Add --rehearsal if that is what is meant (the line is then marked as one).")
     try:
         grp = irl.IpuGroup(d, devices, irl.TRANSPORT_RCCL)
     except irl.RaylibError as e:
@@ -148,11 +154,12 @@ def bench_group(args, torch, irl):
     grp.reset_counters()
     for dev_i in sorted(set(devices)):
         torch.cuda.synchronize(dev_i)
-    step_ms = []
+    step_ms, gather_ms = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         grp.trace(irl.MODE_PATH_TRACE)            # returns when every replica's stream and the gather have drained
         step_ms.append(grp.getTraceTimeSecs() * 1e3)
+        gather_ms.append(grp.last_gather_ms())    # HIP events on the root's stream round the group call (already complete: no wait)
     for dev_i in sorted(set(devices)):
         torch.cuda.synchronize(dev_i)
     elapsed = time.perf_counter() - t0
@@ -169,7 +176,9 @@ def bench_group(args, torch, irl):
                    "parallelism": f"ray bands x{n_gpus}, one process (mi_group_*) on devices {devices}, 1 RCCL send/recv group call per frame"},
         "paths_per_s": c["paths"] / elapsed, "ms_per_frame": elapsed / max(args.steps, 1) * 1e3,
         "casts_per_path": c["casts"] / max(c["paths"], 1), "launch": "group",
-        "step_ms": step_ms, "gather": {"rccl_messages": moved["rccl_messages"], "peer_copies": moved["peer_copies"],
+        "rccl_ranks": {"distinct_devices": len(grp.devices()), "devices": grp.devices(), "backend": "rccl (ncclCommInitAll, one communicator per distinct device)",
+                       "replicas": n_gpus, "rehearsal": len(grp.devices()) != n_gpus},
+        "step_ms": step_ms, "gather_ms": gather_ms, "gather": {"rccl_messages": moved["rccl_messages"], "peer_copies": moved["peer_copies"],
                                         "bytes_to_root": int((n - grp.gathered_device()[1][1]) * irl.TRACE_RESULT.itemsize)},
     }
     rc = 0
@@ -192,12 +201,33 @@ def bench_group(args, torch, irl):
     grp.close()
     out["one_gpu_same_frame_ms"] = one_gpu_same_frame_ms(torch, irl, d, width, height, 0)
     out["roofline"] = {"kernel": "path_trace_wavefront_kernel", "note": "see the N = 1 line: the per-GPU kernel is the same launch on a share of the frame"}
-    print(json.dumps(out), flush=True)
+    emit(out)
     if rc:
         sys.exit(rc)
 
 
+def claim_stdout():
+    """stdout carries exactly ONE JSON line. Native libraries write there too (RCCL prints its version banner on stdout when
+    a communicator is created), so file descriptor 1 is pointed at stderr for the run and the line goes to the real stdout,
+    kept aside here."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    sys.stdout = sys.stderr
+    return real
+
+
+REAL_STDOUT = None
+
+
+def emit(out):
+    REAL_STDOUT.write(json.dumps(out) + "\n")
+    REAL_STDOUT.flush()
+
+
 def main():
+    global REAL_STDOUT
+    REAL_STDOUT = claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -208,6 +238,10 @@ def main():
     ap.add_argument("--weak", action="store_true", help="N>1: N x size^2 pixels instead of config 4's fixed (2 size)^2 frame")
     ap.add_argument("--devices", default="", help="N>1, single-process group path: comma list of HIP ordinals, one per replica (default 0..N-1; "
                                                   "ordinals may repeat - '0,0' rehearses the two-GPU path on a one-GPU box)")
+    ap.add_argument("--launch", default="auto", choices=["auto", "ranks", "group"],
+                    help="N>1: 'ranks' = one process per GPU under torch.distributed.run (what the driver starts; 'auto' takes it when WORLD_SIZE is set); "
+                         "'group' = ONE process driving the N devices through mi_group_* - must be asked for by name")
+    ap.add_argument("--rehearsal", action="store_true", help="allow --devices to repeat an ordinal (several replicas on one GPU); the line is marked as a rehearsal")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend of the ranks launch (nccl = RCCL; gloo with the ranks "
                                                                               "sharing the visible GPUs rehearses the ranks path on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (parity spot check and CPU baseline)")
@@ -230,11 +264,16 @@ def main():
         ge.build_device()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    if world == 1 and args.gpus > 1:
+    if world == 1 and args.gpus > 1 and args.launch == "group":
         return bench_group(args, torch, irl)
+    if args.launch == "group":
+        raise SystemExit("bench.py: --launch group is the single-process form: start it as a plain `python bench.py --gpus N --launch group`, N > 1")
     if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it either as a plain process (single-process "
-                         f"group path) or under torch.distributed.run with --nproc-per-node {args.gpus}")
+        # (a plain `python bench.py --gpus N` does NOT fall into the single-process group launch: that path has never run on two
+        # physical devices, so it has to be asked for by name)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} "
+                         f"--master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...` (one rank per GPU), or ask for the single-process C++ host path "
+                         f"with `--launch group`")
     # one rank per GPU; with --backend gloo (a rehearsal) the ranks may outnumber the visible GPUs and share them
     dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
@@ -285,7 +324,7 @@ def main():
         frame()
     barrier()
     dev.reset_counters()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
@@ -293,10 +332,12 @@ def main():
         dev.run_device(d_rays.data_ptr(), n, irl.MODE_PATH_TRACE, stream.cuda_stream)
         ev[s][1].record(stream)
         gather()
+        ev[s][2].record(stream)       # (the collective's work.wait() made `stream` wait for it: the event is behind the gather)
     barrier()
     elapsed = time.perf_counter() - t0
     counters = dev.counters()
-    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    kernel_ms = [a.elapsed_time(b) for a, b, _ in ev]
+    gather_ms = [b.elapsed_time(c) for _, b, c in ev]
 
     tot = torch.tensor([elapsed, float(counters["casts"]), float(counters["paths"])], dtype=torch.float64, device=coll_dev)
     if dist is not None:
@@ -343,6 +384,11 @@ def main():
     }
     if world > 1:
         out["one_gpu_same_frame_ms"] = one_gpu_same_frame_ms(torch, irl, d, width, height, dev_index)
+        # what the record ran on, so that it cannot pass for something else: ranks of the process group, its backend, and how
+        # many DISTINCT devices they used (gloo rehearsals share the visible GPUs)
+        out["rccl_ranks"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "distinct_devices": min(world, torch.cuda.device_count()) if args.backend == "gloo" else world,
+                             "rehearsal": args.backend != "nccl"}
+        out["gather_ms"] = gather_ms          # rank 0, per step: rgb tiles of every rank to rank 0 (pack + dist.gather), HIP events on the launch stream
 
     # ---------------- roofline of the dominant kernel (the path-trace launch) ----------------
     # Algorithmic bytes per cast: 24 B per node visited + the 42-B primitive record per leaf test + one
@@ -385,10 +431,14 @@ def main():
             lib = gp.build()
             nodes32 = gp.device_nodes(scene)
             gather["attainable_gathers_per_s"] = gp.measure(lib, nodes32, 0, 1, node_lanes)[1]
+            gather["attainable_full_wave"] = gp.measure(lib, nodes32, 0, 1, 64)[1]             # the same walk with all 64 lanes of every wave gathering
             gather["attainable_uniform_random"] = gp.measure(lib, nodes32, 0, 0, node_lanes)[1]
             gather["attainable_from_lds"] = gp.measure(lib, nodes32, 1, 1, node_lanes)[1]
+            gather["attainable_from_lds_full_wave"] = gp.measure(lib, nodes32, 1, 1, 64)[1]
             gather["measured"] = "in this run (ipu_ray_lib_amd/libmi_gather_probe.so)"
-        except Exception as e:      # no probe library and no hipcc here: the committed run of the same probe
+        except (OSError, ge.StaleBinary) as e:      # no probe library here and nothing to build it with: the committed run of the same probe.
+            # (Anything else - a HIP error inside the probe, say - is a failure of this run and propagates.)
+            gather["probe_error"] = f"{type(e).__name__}: {e}"
             pj = json.loads(GATHER_PROBE.read_text()) if GATHER_PROBE.exists() else {"rows": []}
             row = min((r for r in pj["rows"] if r["path"].startswith("L1") and r["walk"] == "tree-shaped" and r["wg_per_cu"] == 5),
                       key=lambda r: abs(r["active_lanes"] - node_lanes), default=None)
@@ -396,10 +446,17 @@ def main():
                 gather["attainable_gathers_per_s"] = row["lane_gathers_per_s"]
                 gather["measured"] = f"offline: {GATHER_PROBE.name} @ {pj.get('source_commit')}, {row['active_lanes']} lanes ({type(e).__name__}: probe not runnable here)"
         att = gather.get("attainable_gathers_per_s")
+        att64 = gather.get("attainable_full_wave")
         roof.update({
             "bound": "l1", "achieved": achieved_gbs, "unit": "GB/s",
             "peak": (att * bytes_per_cast / gathers_per_cast / 1e9) if att else None,
+            # three readings of the same launch, from the most forgiving roof to the strictest:
+            #   frac            against the gather rate of the probe run at K1w's OWN lane count (~33 of 64: the roof embeds the kernel's half-empty waves)
+            #   frac_full_wave  against the same probe with all 64 lanes of every wave gathering (what the L1 path serves a kernel without divergence)
+            #   frac_l2         algorithmic bytes against the guide's 34.5 TB/s aggregate L2 figure (the only on-chip global-load rate in the guide)
             "frac": (gathers_per_s / att) if att else None,
+            "frac_full_wave": (gathers_per_s / att64) if att64 else None,
+            "frac_l2": achieved_gbs / L2_PEAK_GBS,
             "peak_source": "measured: the node-gather microbenchmark csrc/probe/gather_probe.hip (tools/gather_probe.py) - tree-shaped dependent walk over this "
                            "scene's node array, two 16-byte loads per lane, K1w's occupancy and lane count - converted to algorithmic bytes with this "
                            "frame's bytes per gather; MI355X_MICROARCH.md gives no vector-L1 gather rate",
@@ -506,7 +563,7 @@ def main():
         out["cpu_baseline"] = {"value": st.casts / cpu_s, "unit": "rays/s", "cores": cores, "kind": "port",
                                "sample": f"every {step_px}th pixel of the {width}x{height} frame ({cpu_rays.size} pixels) x "
                                          f"{cpu_desc.samples_per_pixel} spp, {st.casts} casts in {cpu_s:.1f} s, oracle/ray_oracle.c (-O3, OpenMP)"}
-    print(json.dumps(out), flush=True)
+    emit(out)
     if dist is not None:
         dist.destroy_process_group()
     if rc:

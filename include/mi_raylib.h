@@ -221,9 +221,13 @@ int mi_scene_set_ray_batch(mi_scene* scene, size_t rays_per_batch);
  *   "tiles"         0 | 1           walk row-structured streams in 8x8 pixel tiles
  *   "seg_budget_kb" N >= 1          partial-sum buffer budget per launch
  *   "nif_spl"       0..128          NIF samples per launch (0 = default)
- *   "nif_shape"     w6 | t6 | t4    workgroup shape of the NIF MLP kernel
+ *   "nif_shape"     w6 | t6 | t4 | r8 | r8s   workgroup shape of the NIF MLP kernel (w6 = default; r8 / r8s = the register-resident
+ *                                   kernel of csrc/nif_regs_kernel.hpp for the network shapes it covers: measured slower, selectable)
  *   "pin"           0 | 1           page-lock the caller's stream for the duration of mi_render
+ *   "nif_overlap"   0 | 1           NIF renders trace sample batch b + 1 beside the MLP of batch b (two slot sets, a second stream; default 1)
  *   "nif_timing"    0 | 1           bracket every MLP launch of a NIF render with HIP events (mi_get_nif_timing)
+ *   "cus"           0..4096         compute units the launch grids are sized for (0 = what the device reports; grids are
+ *                                   units x workgroups resident per unit, asked of the runtime per kernel)
  * None of them changes a result bit. Two further keys select ARITHMETIC:
  *   "double_fallback" 0 | 1         the reference built with -DALLOW_DOUBLE_FALLBACK=1 (CMakeLists.txt:13,34-41; src/Mesh.cpp:38-51):
  *                                   edge functions that are exactly zero in binary32 are recomputed in binary64. Results are those
@@ -282,6 +286,13 @@ int mi_group_reset_counters(mi_group* group);
 /* What the last mi_group_render (or stage call) moved: info[0] = RCCL send/recv pairs, info[1] = peer copies,
  * info[2] = bands dealt, info[3] = host->device copies issued, info[4] = device->host copies issued. */
 int mi_group_last_transfer(const mi_group* group, uint64_t info[5]);
+/* How long the last batch's gather took on the first replica's device, in milliseconds (HIP events on its stream: from
+ * "its own share is traced" to "the last share has arrived" - a slower peer's remaining trace time included). Waits for
+ * that gather. And the communicator the group built: `*distinct` = number of distinct devices (= RCCL ranks when the
+ * transport is RCCL), the ordinals themselves in devices[0..capacity), root first. A multi-GPU record that reports
+ * distinct == 1 was a one-GPU rehearsal (src/IpuScene.cpp:676-684 spreads the batches over real replicas). */
+int mi_group_last_gather_ms(mi_group* group, double* ms);
+int mi_group_devices(const mi_group* group, int32_t* devices, uint32_t capacity, uint32_t* distinct);
 
 /* Thread-local message for the last failing call on this thread. Never NULL. */
 const char* mi_last_error(void);

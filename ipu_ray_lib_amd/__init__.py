@@ -101,7 +101,7 @@ class RaylibError(RuntimeError):
 
 
 _host = None
-_device = None
+_device = {}
 
 
 def _load(path: Path) -> C.CDLL:
@@ -149,10 +149,12 @@ def host_lib() -> C.CDLL:
     return _host
 
 
-def device_lib() -> C.CDLL:
-    """libmi_raylib.so — the HIP kernels. Raises (never falls back) when it is not built."""
+def device_lib(variants: bool = False) -> C.CDLL:
+    """libmi_raylib.so — the HIP kernels. Raises (never falls back) when it is not built.
+    variants=True: libmi_raylib_variants.so, the test build of the same sources with -DMI_RAYLIB_VARIANTS=1, which also
+    carries the kernel families that were measured and not made the default (options kernel 2 / 3, spec, waves, tune, pool_*)."""
     global _device
-    if _device is None:
+    if variants not in _device:
         # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 (same SONAME as the
         # system one libmi_raylib.so links to). Importing torch FIRST makes both resolve to the same
         # already-loaded runtime; the other order leaves torch unable to see the GPU afterwards.
@@ -161,7 +163,10 @@ def device_lib() -> C.CDLL:
         except ImportError:
             pass
         # (MI_RAYLIB_LIB: another build of the same library, for A/B timing of two builds on one box)
-        lib = _load(Path(os.environ["MI_RAYLIB_LIB"]) if os.environ.get("MI_RAYLIB_LIB") else PKG_DIR / "libmi_raylib.so")
+        if variants:
+            lib = _load(PKG_DIR / "libmi_raylib_variants.so")
+        else:
+            lib = _load(Path(os.environ["MI_RAYLIB_LIB"]) if os.environ.get("MI_RAYLIB_LIB") else PKG_DIR / "libmi_raylib.so")
         lib.mi_last_error.restype = C.c_char_p
         lib.mi_version.restype = C.c_char_p
         lib.mi_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
@@ -194,6 +199,8 @@ def device_lib() -> C.CDLL:
         lib.mi_group_trace_time_secs.restype = C.c_double
         lib.mi_group_get_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         lib.mi_group_last_transfer.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        lib.mi_group_last_gather_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        lib.mi_group_devices.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         lib.mi_group_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         lib.mi_group_trace.argtypes = [C.c_void_p, C.c_int]
         lib.mi_group_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -202,8 +209,8 @@ def device_lib() -> C.CDLL:
         lib.mi_get_pool_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         lib.mi_scene_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         lib.mi_get_nif_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
-        _device = lib
-    return _device
+        _device[variants] = lib
+    return _device[variants]
 
 
 def _check_host(status: int):
@@ -368,36 +375,40 @@ class IpuScene:
     """Mirror of the reference's ``IpuScene`` driver object (include/IpuScene.hpp:22-56) over the
     C ABI: construct from a scene description, optionally load a NIF, ``run`` a ray stream."""
 
-    def __init__(self, desc: SceneDesc):
-        self._lib = device_lib()
+    def __init__(self, desc: SceneDesc, variants: bool = False):
+        self._lib = device_lib(variants)
         self._h = C.c_void_p()
         self.desc = desc
-        _check_dev(self._lib.mi_scene_create(C.byref(desc), C.byref(self._h)))
+        self._check(self._lib.mi_scene_create(C.byref(desc), C.byref(self._h)))
+
+    def _check(self, status: int):
+        if status != MI_OK:
+            raise RaylibError(f"mi_raylib call failed ({status}): {self._lib.mi_last_error().decode()}")
 
     # -- reference API names -------------------------------------------------------------
     @classmethod
-    def from_blob(cls, blob: np.ndarray, extras: SceneDesc) -> "IpuScene":
+    def from_blob(cls, blob: np.ndarray, extras: SceneDesc, variants: bool = False) -> "IpuScene":
         """Scene from the reference's serialised byte stream + the fields that are not part of it."""
         self = cls.__new__(cls)
-        self._lib = device_lib()
+        self._lib = device_lib(variants)
         self._h = C.c_void_p()
         self.desc = extras
         b = np.ascontiguousarray(blob, dtype=np.uint8)
-        _check_dev(self._lib.mi_scene_create_from_blob(b.ctypes.data, b.size, C.byref(extras), C.byref(self._h)))
+        self._check(self._lib.mi_scene_create_from_blob(b.ctypes.data, b.size, C.byref(extras), C.byref(self._h)))
         return self
 
     def setHdriRotation(self, degrees: float):
-        _check_dev(self._lib.mi_scene_set_hdri_rotation(self._h, float(degrees)))
+        self._check(self._lib.mi_scene_set_hdri_rotation(self._h, float(degrees)))
 
     def setMaxNifBatchSize(self, rays_per_batch: int):
-        _check_dev(self._lib.mi_scene_set_max_nif_batch(self._h, int(rays_per_batch)))
+        self._check(self._lib.mi_scene_set_max_nif_batch(self._h, int(rays_per_batch)))
 
     def setRayBatch(self, rays_per_batch: int):
-        _check_dev(self._lib.mi_scene_set_ray_batch(self._h, int(rays_per_batch)))
+        self._check(self._lib.mi_scene_set_ray_batch(self._h, int(rays_per_batch)))
 
     def set_option(self, key: str, value) -> "IpuScene":
         """Kernel selection / tuning of THIS scene (mi_scene_set_option); never changes a result bit."""
-        _check_dev(self._lib.mi_scene_set_option(self._h, key.encode(), str(value).encode()))
+        self._check(self._lib.mi_scene_set_option(self._h, key.encode(), str(value).encode()))
         return self
 
     def getTraceTimeSecs(self) -> float:
@@ -424,7 +435,7 @@ class IpuScene:
         cols = np.array([k.shape[1] for k in ks], dtype=np.uint32)
         rl = np.array([1 if r else 0 for r in relu], dtype=np.uint8)
         mean_a = np.ascontiguousarray(mean, dtype=np.float32)
-        _check_dev(self._lib.mi_scene_set_nif(self._h, n, kp, bp, rows.ctypes.data, cols.ctypes.data, rl.ctypes.data,
+        self._check(self._lib.mi_scene_set_nif(self._h, n, kp, bp, rows.ctypes.data, cols.ctypes.data, rl.ctypes.data,
                                               int(embedding_dimension), float(max_value), mean_a.ctypes.data,
                                               1 if log_tonemap else 0))
 
@@ -439,24 +450,24 @@ class IpuScene:
             base = rays.ctypes.data
             proto = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t)
             cb = proto(lambda user, idx, ptr, cnt: callback(idx, (ptr - base) // TRACE_RESULT.itemsize, cnt))
-        _check_dev(self._lib.mi_render(self._h, mode, rays.ctypes.data, rays.size, cb, None))
+        self._check(self._lib.mi_render(self._h, mode, rays.ctypes.data, rays.size, cb, None))
         return rays
 
     def run_device(self, d_rays_ptr: int, n: int, mode: int, stream: int = 0):
         """Trace a DEVICE-resident ray stream (e.g. a torch uint8 tensor's data_ptr) asynchronously."""
-        _check_dev(self._lib.mi_render_device(self._h, mode, C.c_void_p(d_rays_ptr), n, C.c_void_p(stream)))
+        self._check(self._lib.mi_render_device(self._h, mode, C.c_void_p(d_rays_ptr), n, C.c_void_p(stream)))
 
     def nif_infer_device(self, d_u: int, d_v: int, d_bgr: int, n: int, stream: int = 0):
-        _check_dev(self._lib.mi_nif_infer_device(self._h, C.c_void_p(d_u), C.c_void_p(d_v), C.c_void_p(d_bgr), n, C.c_void_p(stream)))
+        self._check(self._lib.mi_nif_infer_device(self._h, C.c_void_p(d_u), C.c_void_p(d_v), C.c_void_p(d_bgr), n, C.c_void_p(stream)))
 
     def counters(self) -> dict:
         c = (C.c_uint64 * 4)()
-        _check_dev(self._lib.mi_get_counters(self._h, c))
+        self._check(self._lib.mi_get_counters(self._h, c))
         return {"casts": c[0], "nodes_visited": c[1], "leaf_tests": c[2], "paths": c[3]}
 
     def phase_stats(self) -> dict:
         c = (C.c_uint64 * 12)()
-        _check_dev(self._lib.mi_get_phase_stats(self._h, c))
+        self._check(self._lib.mi_get_phase_stats(self._h, c))
         names = ("node", "leaf", "shade", "gen")
         out = {n: {"iters": c[2 * i], "lanes": c[2 * i + 1]} for i, n in enumerate(names)}
         out["cycles"] = {"traverse": c[8], "shade": c[9], "gen": c[10], "total": c[11]}
@@ -464,17 +475,17 @@ class IpuScene:
 
     def pool_stats(self) -> dict:
         c = (C.c_uint64 * 8)()
-        _check_dev(self._lib.mi_get_pool_stats(self._h, c))
+        self._check(self._lib.mi_get_pool_stats(self._h, c))
         return dict(zip(("loops", "refill_turns", "refill_lanes", "idle", "lost_claims", "bursts", "burst_lanes", "refill_cycles"), [int(x) for x in c]))
 
     def nif_timing(self) -> dict:
         """Milliseconds in MLP launches (and their number) since the last call; needs set_option("nif_timing", 1)."""
         c = (C.c_double * 2)()
-        _check_dev(self._lib.mi_get_nif_timing(self._h, c))
+        self._check(self._lib.mi_get_nif_timing(self._h, c))
         return {"mlp_ms": float(c[0]), "launches": int(c[1])}
 
     def reset_counters(self):
-        _check_dev(self._lib.mi_reset_counters(self._h))
+        self._check(self._lib.mi_reset_counters(self._h))
 
     def close(self):
         if self._h:
@@ -491,8 +502,8 @@ class IpuScene:
 class _BorrowedScene(IpuScene):
     """A replica's scene handle inside an IpuGroup (owned by the group: never destroyed from here)."""
 
-    def __init__(self, handle, desc):
-        self._lib = device_lib()
+    def __init__(self, handle, desc, lib=None):
+        self._lib = lib if lib is not None else device_lib()
         self._h = C.c_void_p(handle)
         self.desc = desc
 
@@ -508,18 +519,20 @@ class IpuGroup:
     of `devices` (ordinals may repeat), the host ray stream dealt to them in 8-row bands, one RCCL gather to the first
     replica's device at frame end (mi_group_* in include/mi_raylib.h)."""
 
-    def __init__(self, desc: SceneDesc, devices, transport: int = TRANSPORT_AUTO):
-        self._lib = device_lib()
+    def __init__(self, desc: SceneDesc, devices, transport: int = TRANSPORT_AUTO, variants: bool = False):
+        self._lib = device_lib(variants)
         self._h = C.c_void_p()
         self.desc = desc
         dv = np.ascontiguousarray(devices, dtype=np.int32)
-        _check_dev(self._lib.mi_group_create(C.byref(desc), dv.ctypes.data, dv.size, int(transport), C.byref(self._h)))
+        self._check(self._lib.mi_group_create(C.byref(desc), dv.ctypes.data, dv.size, int(transport), C.byref(self._h)))
+
+    _check = IpuScene._check
 
     def scenes(self):
-        return [_BorrowedScene(self._lib.mi_group_scene(self._h, i), self.desc) for i in range(self._lib.mi_group_size(self._h))]
+        return [_BorrowedScene(self._lib.mi_group_scene(self._h, i), self.desc, self._lib) for i in range(self._lib.mi_group_size(self._h))]
 
     def setRayBatch(self, rays_per_batch: int):
-        _check_dev(self._lib.mi_group_set_ray_batch(self._h, int(rays_per_batch)))
+        self._check(self._lib.mi_group_set_ray_batch(self._h, int(rays_per_batch)))
 
     # The NIF model and its settings go to EVERY replica, as the reference streams the weights to every replica of the
     # replicated graph (src/IpuScene.cpp:535) - what mi::IpuScene::configure does in the C++ host (csrc/host/IpuScene.hpp).
@@ -548,7 +561,7 @@ class IpuGroup:
             base = rays.ctypes.data
             proto = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t)
             cb = proto(lambda user, idx, ptr, cnt: callback(idx, (ptr - base) // TRACE_RESULT.itemsize, cnt))
-        _check_dev(self._lib.mi_group_render(self._h, mode, rays.ctypes.data, rays.size, cb, None))
+        self._check(self._lib.mi_group_render(self._h, mode, rays.ctypes.data, rays.size, cb, None))
         return rays
 
     def getTraceTimeSecs(self) -> float:
@@ -556,25 +569,38 @@ class IpuGroup:
 
     def counters(self) -> dict:
         c = (C.c_uint64 * 4)()
-        _check_dev(self._lib.mi_group_get_counters(self._h, c))
+        self._check(self._lib.mi_group_get_counters(self._h, c))
         return {"casts": c[0], "nodes_visited": c[1], "leaf_tests": c[2], "paths": c[3]}
 
     def last_transfer(self) -> dict:
         c = (C.c_uint64 * 5)()
-        _check_dev(self._lib.mi_group_last_transfer(self._h, c))
+        self._check(self._lib.mi_group_last_transfer(self._h, c))
         return {"rccl_messages": c[0], "peer_copies": c[1], "bands": c[2], "upload_copies": c[3], "download_copies": c[4]}
+
+    def last_gather_ms(self) -> float:
+        """Milliseconds the last batch's gather took as the first replica's device saw it (HIP events on its stream)."""
+        ms = C.c_double()
+        self._check(self._lib.mi_group_last_gather_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def devices(self):
+        """The distinct device ordinals of the group's communicator, root first (RCCL ranks when the transport is RCCL)."""
+        n = C.c_uint32()
+        buf = np.zeros(64, np.int32)
+        self._check(self._lib.mi_group_devices(self._h, buf.ctypes.data, buf.size, C.byref(n)))
+        return [int(x) for x in buf[:n.value]]
 
     # -- the stages one by one: the shares stay resident on the devices between calls --
     def upload(self, rays: np.ndarray):
         assert rays.dtype == TRACE_RESULT and rays.flags["C_CONTIGUOUS"]
-        _check_dev(self._lib.mi_group_upload(self._h, rays.ctypes.data, rays.size))
+        self._check(self._lib.mi_group_upload(self._h, rays.ctypes.data, rays.size))
 
     def trace(self, mode: int = MODE_PATH_TRACE):
-        _check_dev(self._lib.mi_group_trace(self._h, mode))
+        self._check(self._lib.mi_group_trace(self._h, mode))
 
     def download(self, rays: np.ndarray) -> np.ndarray:
         assert rays.dtype == TRACE_RESULT and rays.flags["C_CONTIGUOUS"]
-        _check_dev(self._lib.mi_group_download(self._h, rays.ctypes.data, rays.size))
+        self._check(self._lib.mi_group_download(self._h, rays.ctypes.data, rays.size))
         return rays
 
     def gathered_device(self):
@@ -582,11 +608,11 @@ class IpuGroup:
         ptr = C.c_void_p()
         n = self._lib.mi_group_size(self._h)
         off = (C.c_uint64 * (n + 1))()
-        _check_dev(self._lib.mi_group_gathered_device(self._h, C.byref(ptr), off, n + 1))
+        self._check(self._lib.mi_group_gathered_device(self._h, C.byref(ptr), off, n + 1))
         return ptr.value, [int(x) for x in off]
 
     def reset_counters(self):
-        _check_dev(self._lib.mi_group_reset_counters(self._h))
+        self._check(self._lib.mi_group_reset_counters(self._h))
 
     def close(self):
         if self._h:

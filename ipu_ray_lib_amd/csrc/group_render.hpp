@@ -75,6 +75,7 @@ struct mi_group {
   bool useRccl = false;
   mi_trace_result* d_gather = nullptr; size_t gatherCap = 0;      // on the root device: the shares, replica after replica
   hipEvent_t gathered = nullptr;               // root stream: the last gather (and, when one followed, its download) is done
+  hipEvent_t gatherBegin = nullptr, gatherEnd = nullptr;      // root stream, timing: round the last batch's group call / peer copies
   bool gatherPending = false;
   Plan resident;                               // what mi_group_upload left on the devices (n = 0: nothing)
   bool residentTraced = false;                 // ... and whether it has been traced and gathered since
@@ -97,6 +98,8 @@ struct mi_group {
     if (!replicas.empty()) (void)hipSetDevice(replicas[0].device);
     if (d_gather) (void)hipFree(d_gather);
     if (gathered) (void)hipEventDestroy(gathered);
+    if (gatherBegin) (void)hipEventDestroy(gatherBegin);
+    if (gatherEnd) (void)hipEventDestroy(gatherEnd);
   }
 };
 
@@ -205,6 +208,10 @@ void groupStageTrace(mi_group& G, const mi_group::Plan& pl, int mode) {
 void groupStageGather(mi_group& G, const mi_group::Plan& pl) {
   const uint32_t R = (uint32_t)G.replicas.size();
   mi_group::Replica& root = G.replicas[0];
+  // (timing events on the root's stream: `gatherBegin` fires when the root's own share is traced, `gatherEnd` when the
+  // last share has arrived - the gather as the frame sees it, a slower peer's remaining trace time included)
+  HIP_CHECK(hipSetDevice(root.device));
+  HIP_CHECK(hipEventRecord(G.gatherBegin, root.stream));
   if (R > 1) {
     if (G.useRccl) {
       // Inside the group call every communicator (= device) uses ONE stream: that of the device's first replica,
@@ -246,6 +253,7 @@ void groupStageGather(mi_group& G, const mi_group::Plan& pl) {
     }
   }
   HIP_CHECK(hipSetDevice(root.device));
+  HIP_CHECK(hipEventRecord(G.gatherEnd, root.stream));
   HIP_CHECK(hipEventRecord(G.gathered, root.stream));
   G.gatherPending = true;
 }
@@ -362,6 +370,8 @@ int mi_group_create(const mi_scene_desc* desc, const int32_t* devices, uint32_t 
     G->sent.assign(G->commDevices.size(), nullptr);
     HIP_CHECK(hipSetDevice(G->replicas[0].device));
     HIP_CHECK(hipEventCreateWithFlags(&G->gathered, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreate(&G->gatherBegin));
+    HIP_CHECK(hipEventCreate(&G->gatherEnd));
     // transport: 0 = automatic (RCCL as soon as more than one device takes part), 1 = RCCL always (replicas that share
     // the root's device then send to themselves: the one-GPU rehearsal of the collective), 2 = peer copies only
     G->useRccl = num_replicas > 1 && (transport == 1 || (transport == 0 && G->commDevices.size() > 1));
@@ -478,6 +488,25 @@ int mi_group_get_counters(mi_group* group, uint64_t counts[4]) {
 int mi_group_reset_counters(mi_group* group) {
   if (!group) { g_err = "mi_group_reset_counters: null group"; return MI_ERR_INVALID_ARG; }
   for (auto& P : group->replicas) { const int rc = mi_reset_counters(P.scene); if (rc != MI_OK) return rc; }
+  return MI_OK;
+}
+
+int mi_group_last_gather_ms(mi_group* group, double* ms) {
+  if (!group || !ms) { g_err = "mi_group_last_gather_ms: null argument"; return MI_ERR_INVALID_ARG; }
+  if (!group->gatherPending) { g_err = "mi_group_last_gather_ms: nothing has been gathered yet"; return MI_ERR_INVALID_ARG; }
+  return guarded([&] {
+    HIP_CHECK(hipSetDevice(group->replicas[0].device));
+    HIP_CHECK(hipEventSynchronize(group->gatherEnd));
+    float f = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&f, group->gatherBegin, group->gatherEnd));
+    *ms = f;
+  });
+}
+
+int mi_group_devices(const mi_group* group, int32_t* devices, uint32_t capacity, uint32_t* distinct) {
+  if (!group || !distinct) { g_err = "mi_group_devices: null argument"; return MI_ERR_INVALID_ARG; }
+  *distinct = (uint32_t)group->commDevices.size();
+  for (uint32_t i = 0; devices && i < capacity && i < group->commDevices.size(); ++i) devices[i] = group->commDevices[i];
   return MI_OK;
 }
 

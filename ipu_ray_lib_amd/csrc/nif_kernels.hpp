@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "ray_math.h"
+#include "nif_regs_pack.hpp"
 #include "../../include/mi_raylib.h"
 
 #ifndef MI_NIF_STAMPS
@@ -58,7 +59,6 @@ __device__ __forceinline__ unsigned long long nif_now() {
 #define MI_STAMP_ADD(slot, a, b)
 #endif
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));   // a 16-byte fragment as the asm statements of the k-loop see it (legal as an in/out operand; 8 halves are not)
@@ -68,7 +68,6 @@ typedef uint32_t u4v __attribute__((ext_vector_type(4)));   // a 16-byte fragmen
 //                  workgroup and feeds 6 MFMAs. Needs 96 x (stride + 32) x 2 B of LDS per workgroup.
 //   t6, t4       : 8 waves = 4 output-feature groups x 2 row groups of 96 / 64 rays (t4: any width up to 384).
 constexpr uint32_t kNifMaxLdsBytes = 160 * 1024 - 2048;   // dynamic LDS: what is left beside the static coordinate staging (2 x 192 floats)
-constexpr uint32_t kNifMaxLayers = 16;
 constexpr uint32_t kNifMaxTilesPerWave = 6;   // output-feature tiles (of 16) per wave: supports widths up to 384
 
 struct NifLayerDesc {
@@ -94,9 +93,11 @@ struct NifDevice {
   uint32_t* d_index = nullptr;     // compacted ray indices
   size_t indexCap = 0;
   bool ok = false;
+  NifRegsDevice regs;              // the same model packed for K3r (nif_regs_kernel.hpp); regs.ok only for the shapes that kernel covers
 
   bool loaded() const { return ok; }
   void release() {
+    regs.release();
     if (d_weights) (void)hipFree(d_weights);
     if (d_count) (void)hipFree(d_count);
     if (d_index) (void)hipFree(d_index);
@@ -168,6 +169,7 @@ struct NifDevice {
     if (hipMalloc(&d_weights, packed.size() * sizeof(_Float16)) != hipSuccess) throw std::runtime_error("NIF: hipMalloc failed");
     (void)hipMemcpy(d_weights, packed.data(), packed.size() * sizeof(_Float16), hipMemcpyHostToDevice);
     if (hipMalloc(&d_count, sizeof(uint32_t)) != hipSuccess) throw std::runtime_error("NIF: hipMalloc failed");
+    (void)regs.load(numLayers, kernels, biases, rows, cols, relu, embedDim, maxValue, mean, logTonemap);
     p = P;
     ok = true;
   }
@@ -587,10 +589,19 @@ __global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : 1) nif_ml
 #endif
 }
 
+inline void nif_regs_launch(const NifRegsDevice& nr, const float* u, const float* v, const uint32_t* idx, const uint32_t* countPtr,
+                            uint32_t numRows, float* bgrOut, mi_trace_result* rays, hipStream_t stream, bool scatter, uint32_t numCUs, uint32_t variant);      // nif_regs_kernel.hpp
+
 // bgrOut: result of row r at bgrOut[3r..] - or, with `scatter`, at bgrOut[3*idx[r]..] (the row's own slot)
+// shape (scene option "nif_shape"): 0 = w6 (default), 1 = t6, 2 = t4 (nif_mlp_kernel's workgroup shapes); 4 = r8, 5 = r8s = K3r, the
+// register-resident kernel of nif_regs_kernel.hpp (eight waves in lock-step / waves 4-7 staggered by a quarter chunk), for the
+// network shapes it covers - measured 6 % (r8) and 15 % (r8s) SLOWER than w6 (profiles/r04_k3r_attempt.txt), so never the default;
+// a network it does not cover runs w6
 inline void nif_launch_mlp(const NifDevice& nif, const float* u, const float* v, const uint32_t* idx, const uint32_t* countPtr,
-                           uint32_t numRows, float* bgrOut, mi_trace_result* rays, hipStream_t stream, bool scatter = false, uint32_t shape = 0) {
+                           uint32_t numRows, float* bgrOut, mi_trace_result* rays, hipStream_t stream, bool scatter = false, uint32_t shape = 0, uint32_t numCUs = 256) {
   if (numRows == 0) return;
+  if (shape >= 4 && nif.regs.ok) { nif_regs_launch(nif.regs, u, v, idx, countPtr, numRows, bgrOut, rays, stream, scatter, numCUs, shape == 5 ? 0u : 1u); return; }
+  if (shape >= 3) shape = 0;
   uint32_t maxTiles = 1;
   for (uint32_t l = 0; l < nif.p.numLayers; ++l) maxTiles = std::max(maxTiles, nif.p.layers[l].nTiles / 4);
   // shape: MT ray tiles per wave x RG row groups. Scene option "nif_shape" = w6|t6|t4 (`shape` 0|1|2) overrides the default (w6).
@@ -606,8 +617,11 @@ inline void nif_launch_mlp(const NifDevice& nif, const float* u, const float* v,
 #if MI_NIF_STAMPS
     if (getenv("MI_NIF_DIAG_ONE_WG")) lds = kNifMaxLdsBytes;   // diagnostic: one workgroup per CU, i.e. one wave per SIMD for the 4-wave shape
 #endif
+    // grid-stride: four generations of the workgroups that stay resident (two per compute unit for the 4-wave shape - the LDS
+    // image sets that -, one for the 8-wave shapes), so a workgroup that finishes early leaves its slot to a waiting one
     uint32_t blocks = (numRows + rowsPerPass - 1) / rowsPerPass;
-    if (blocks > 256 * 8) blocks = 256 * 8;          // grid-stride beyond 8 passes per CU
+    const uint32_t cap = numCUs * (threads == 256 ? 2u : 1u) * 4u;
+    if (blocks > cap) blocks = cap;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNifMaxLdsBytes);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, nif.p, nif.d_weights, u, v, idx, countPtr, numRows, bgrOut, rays, scatter);
   };
@@ -671,21 +685,21 @@ __global__ void __launch_bounds__(256) nif_segment_roll_kernel(mi_trace_result* 
 }
 
 // mi_nif_infer_device: every row is evaluated (no compaction)
-inline void nif_infer(NifDevice& nif, const float* d_u, const float* d_v, float* d_bgr, size_t n, size_t maxBatch, hipStream_t stream, uint32_t shape = 0) {
+inline void nif_infer(NifDevice& nif, const float* d_u, const float* d_v, float* d_bgr, size_t n, size_t maxBatch, hipStream_t stream, uint32_t shape = 0, uint32_t numCUs = 256) {
   const size_t chunk = maxBatch ? maxBatch : n;
   for (size_t off = 0; off < n; off += chunk) {
     const size_t cnt = (n - off < chunk) ? (n - off) : chunk;
-    nif_launch_mlp(nif, d_u + off, d_v + off, nullptr, nullptr, (uint32_t)cnt, d_bgr + 3 * off, nullptr, stream, false, shape);
+    nif_launch_mlp(nif, d_u + off, d_v + off, nullptr, nullptr, (uint32_t)cnt, d_bgr + 3 * off, nullptr, stream, false, shape, numCUs);
   }
 }
 
 // One sample's environment pass over the whole ray stream (src/IpuScene.cpp:571-583)
 inline void nif_env_pass(NifDevice& nif, mi_trace_result* d_rays, uint32_t n, float azimuthRadians, float* d_u, float* d_v,
-                         float* d_bgr, size_t /*maxBatch*/, hipStream_t stream, uint32_t shape = 0) {
+                         float* d_bgr, size_t /*maxBatch*/, hipStream_t stream, uint32_t shape = 0, uint32_t numCUs = 256) {
   nif.ensureIndex(n);
   (void)hipMemsetAsync(nif.d_count, 0, sizeof(uint32_t), stream);
   hipLaunchKernelGGL(escaped_uv_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_rays, n, azimuthRadians, d_u, d_v, nif.d_index, nif.d_count);
-  nif_launch_mlp(nif, d_u, d_v, nif.d_index, nif.d_count, n, nullptr, d_rays, stream, false, shape);
+  nif_launch_mlp(nif, d_u, d_v, nif.d_index, nif.d_count, n, nullptr, d_rays, stream, false, shape, numCUs);
 }
 
 }  // namespace mi

@@ -68,8 +68,12 @@ template <int PATH, int WALK>
 double run(const Node32* d_nodes, uint32_t numNodes, uint32_t steps, uint32_t activeLanes, uint32_t ldsNodes, uint32_t blocks, size_t ldsBytes, uint32_t* d_sink, int reps) {
   auto k = gather_probe_kernel<PATH, WALK>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
-  hipEvent_t e0, e1;
-  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  struct Events {      // destroyed on every path out of this function
+    hipEvent_t a = nullptr, b = nullptr;
+    ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  } ev;
+  CK(hipEventCreate(&ev.a)); CK(hipEventCreate(&ev.b));
+  hipEvent_t e0 = ev.a, e1 = ev.b;
   hipLaunchKernelGGL(k, dim3(blocks), dim3(256), ldsBytes, 0, d_nodes, numNodes, steps, activeLanes, ldsNodes, d_sink);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0, 0));
@@ -78,7 +82,6 @@ double run(const Node32* d_nodes, uint32_t numNodes, uint32_t steps, uint32_t ac
   CK(hipDeviceSynchronize());
   float ms = 0.f;
   CK(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return ms / reps;
 }
 
@@ -90,8 +93,12 @@ extern "C" double gp_run(const void* nodes, uint32_t numNodes, int path, int wal
                           uint32_t wgPerCU, int reps, uint32_t* outBlocks) {
   int cus = 256;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
-  Node32* d_nodes = nullptr; uint32_t* d_sink = nullptr;
-  CK(hipMalloc(&d_nodes, (size_t)numNodes * 32)); CK(hipMalloc(&d_sink, 4096));
+  struct Buffers {     // freed on every path out of this function, the error returns included
+    Node32* nodes = nullptr; uint32_t* sink = nullptr;
+    ~Buffers() { if (nodes) (void)hipFree(nodes); if (sink) (void)hipFree(sink); }
+  } buf;
+  CK(hipMalloc(&buf.nodes, (size_t)numNodes * 32)); CK(hipMalloc(&buf.sink, 4096));
+  Node32* const d_nodes = buf.nodes; uint32_t* const d_sink = buf.sink;
   CK(hipMemcpy(d_nodes, nodes, (size_t)numNodes * 32, hipMemcpyHostToDevice));
   // an LDS request of 160 KiB / (W + 1/2), rounded down to whole KiB: W workgroups fit a CU with room to spare, W + 1 do not
   const size_t ldsBytes = (size_t)(2 * 160 * 1024) / (2 * wgPerCU + 1) / 1024 * 1024;
@@ -108,6 +115,5 @@ extern "C" double gp_run(const void* nodes, uint32_t numNodes, int path, int wal
     case 5: ms = run<2, 1>(d_nodes, numNodes, steps, activeLanes, ldsNodes, blocks, ldsBytes, d_sink, reps); break;
     default: break;
   }
-  (void)hipFree(d_nodes); (void)hipFree(d_sink);
   return ms;
 }

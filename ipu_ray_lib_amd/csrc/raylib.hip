@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -15,8 +16,18 @@
 #include "ray_math.h"
 #include "trace_kernels.hpp"
 #include "trace_wavefront.hpp"
+// MI_RAYLIB_VARIANTS=1 (libmi_raylib_variants.so, the test build): the kernel families that were built, measured and not
+// made the default - LDS-staged nodes (kernel 2), the path pool (kernel 3), the speculative walk (spec), the 4-wave and
+// the runtime-weights instantiations (waves, tune) - stay selectable and parity-tested there. The
+// shipped library carries the default path, its instrumented build, the nested-loop kernel and the two arithmetic options.
+#ifndef MI_RAYLIB_VARIANTS
+#define MI_RAYLIB_VARIANTS 0
+#endif
+#if MI_RAYLIB_VARIANTS
 #include "trace_pool.hpp"
+#endif
 #include "nif_kernels.hpp"
+#include "nif_regs_kernel.hpp"
 #include "scene_blob.hpp"
 
 using namespace mi;
@@ -79,8 +90,12 @@ const float* hostSinTable() {
 struct SceneOptions {
   bool fullStats = false;          // MI_RAYLIB_FULL_STATS / "full_stats": instrumented kernel variants (node/leaf counters, phase occupancy)
   WaveTune tune = kDefaultTune;
-  int kernelChoice = 1;            // MI_RAYLIB_KERNEL / "kernel": 0 = nested-loop kernel, 1 = wavefront (global nodes), 2 = wavefront + LDS-staged nodes, 3 = path pool (trace_pool.hpp)
+  int kernelChoice = 1;            // MI_RAYLIB_KERNEL / "kernel": 0 = nested-loop kernel, 1 = wavefront (global nodes); variants build: 2 = wavefront + LDS-staged nodes, 3 = path pool (trace_pool.hpp)
+#if MI_RAYLIB_VARIANTS
   PoolTune poolTune;               // MI_RAYLIB_POOL_TUNE / "pool_tune": leafAt,burst,retireAt,refillMin,shadeW,genW[,dbl,maxExtra,leafThenNode,prio]
+#endif
+  uint32_t cus = 0;                // "cus": compute units the launch grids are sized for (0 = what the device reports)
+  std::string why;                 // why the last set() returned false
   int poolWaves = 4;               // MI_RAYLIB_POOL_WAVES / "pool_waves": waves per workgroup of the path-pool kernel, 4 | 8 | 16 (400 | 800 | 1600 slots)
   int wavesPerSimd = 5;            // MI_RAYLIB_WAVES / "waves": 4 = the 108-VGPR build of the default kernel
   bool specLeaf = false;           // MI_RAYLIB_SPEC / "spec": lanes walk on past ONE pending primitive test (trace_wavefront.hpp, SPEC)
@@ -88,7 +103,8 @@ struct SceneOptions {
   size_t segBudgetKb = (size_t)8 * 1024 * 1024;   // MI_RAYLIB_SEG_BUDGET_KB / "seg_budget_kb": partial-sum buffer budget per launch
   uint32_t nifSamplesPerLaunch = 0;               // MI_RAYLIB_NIF_SPL / "nif_spl": 0 = default (128, memory permitting)
   bool pin = true;                 // MI_RAYLIB_PIN / "pin": page-lock the caller's stream for the duration of mi_render
-  uint32_t nifShape = 0;           // MI_RAYLIB_NIF_SHAPE / "nif_shape": 0 = w6 (default), 1 = t6, 2 = t4
+  uint32_t nifShape = 0;           // MI_RAYLIB_NIF_SHAPE / "nif_shape": 0 = w6 (default), 1 = t6, 2 = t4; 4 = r8, 5 = r8s (K3r, nif_regs_kernel.hpp: measured slower, selectable)
+  bool nifOverlap = true;          // "nif_overlap": NIF renders trace sample batch b + 1 beside the MLP of batch b (two slot sets, second stream)
   bool nifTiming = false;          // "nif_timing": HIP events round every MLP launch of a NIF render (mi_get_nif_timing)
   // the two options that select ARITHMETIC (every other option leaves every result bit alone):
   bool doubleFallback = false;     // "double_fallback": the reference's ALLOW_DOUBLE_FALLBACK=1 build (CMakeLists.txt:13,34-41; Mesh.cpp:38-51), bit-exact to the oracle in that mode
@@ -110,9 +126,18 @@ struct SceneOptions {
     return true;
   }
   bool set(const std::string& key, const char* v) {
+    why = "unknown option or bad value";
     if (!v) return false;
     unsigned long long q = 0;
-    if (key == "full_stats") return flag01(v, fullStats);
+    // (an instrumented launch, a NIF launch and the double_fallback build have no tolerance-tier kernel: the combination is
+    // refused where it is asked for instead of rendering another tier than the scene reports)
+    if (key == "full_stats") {
+      bool b = fullStats;
+      if (!flag01(v, b)) return false;
+      if (b && fast) { why = "full_stats cannot be combined with fast (the tolerance tier has no instrumented build)"; return false; }
+      fullStats = b; return true;
+    }
+#if MI_RAYLIB_VARIANTS
     if (key == "kernel") { if (!number(v, 0, 3, q)) return false; kernelChoice = (int)q; return true; }
     if (key == "pool_waves") { if (!number(v, 4, 16, q) || (q != 4 && q != 8 && q != 16)) return false; poolWaves = (int)q; return true; }
     if (key == "pool_tune") {
@@ -123,18 +148,44 @@ struct SceneOptions {
     }
     if (key == "waves") { if (!number(v, 4, 5, q)) return false; wavesPerSimd = (int)q; return true; }
     if (key == "spec") return flag01(v, specLeaf);
+#else
+    if (key == "kernel") {
+      if (!number(v, 0, 3, q)) return false;
+      if (q > 1) { why = "kernel 2 / 3 are not compiled into this library (the variants build, -DMI_RAYLIB_VARIANTS=1, has them)"; return false; }
+      kernelChoice = (int)q; return true;
+    }
+    if (key == "pool_waves" || key == "pool_tune" || key == "tune") { why = "not compiled into this library (the variants build, -DMI_RAYLIB_VARIANTS=1, has it)"; return false; }
+    if (key == "waves") { if (!number(v, 4, 5, q)) return false; if (q != 5) { why = "the 4-wave build is not compiled into this library (variants build)"; return false; } return true; }
+    if (key == "spec") { bool b = false; if (!flag01(v, b)) return false; if (b) { why = "the speculative walk is not compiled into this library (variants build)"; return false; } return true; }
+#endif
+    if (key == "cus") { if (!number(v, 0, 4096, q)) return false; cus = (uint32_t)q; return true; }
     if (key == "tiles") return flag01(v, tiles);
     if (key == "seg_budget_kb") { if (!number(v, 1, ~0ull >> 12, q)) return false; segBudgetKb = (size_t)q; return true; }
     if (key == "nif_spl") { if (!number(v, 0, 128, q)) return false; nifSamplesPerLaunch = (uint32_t)q; return true; }
     if (key == "pin") return flag01(v, pin);
     if (key == "nif_timing") return flag01(v, nifTiming);
-    if (key == "double_fallback") return flag01(v, doubleFallback);
-    if (key == "fast") return flag01(v, fast);
+    if (key == "nif_overlap") return flag01(v, nifOverlap);
+    if (key == "double_fallback") {
+      bool b = doubleFallback;
+      if (!flag01(v, b)) return false;
+      if (b && fast) { why = "double_fallback cannot be combined with fast"; return false; }
+      doubleFallback = b; return true;
+    }
+    if (key == "fast") {
+      bool b = fast;
+      if (!flag01(v, b)) return false;
+      if (b && (fullStats || doubleFallback)) { why = "fast cannot be combined with full_stats or double_fallback"; return false; }
+#if MI_RAYLIB_VARIANTS
+      if (b && (kernelChoice != 1 || specLeaf || wavesPerSimd != 5 || !(tune == kDefaultTune))) { why = "fast is a build of the default kernel only (kernel 1, 5 waves, default weights, no spec)"; return false; }
+#endif
+      fast = b; return true;
+    }
     if (key == "nif_shape") {
       const std::string s(v);
-      if (s == "w6") nifShape = 0; else if (s == "t6") nifShape = 1; else if (s == "t4") nifShape = 2; else return false;
+      if (s == "w6") nifShape = 0; else if (s == "t6") nifShape = 1; else if (s == "t4") nifShape = 2; else if (s == "r8") nifShape = 4; else if (s == "r8s") nifShape = 5; else return false;
       return true;
     }
+#if MI_RAYLIB_VARIANTS
     if (key == "tune") {      // leafAt,shadeAt,genAt[,burst,keep8,dbl,maxExtra,leafThenNode,prio,leafP]
       unsigned a, b, c, dd = 48, k8 = 3, db = 4, mx = 6, ln = 1, pr = 1, lp = 40;
       if (sscanf(v, "%u,%u,%u,%u,%u,%u,%u,%u,%u,%u", &a, &b, &c, &dd, &k8, &db, &mx, &ln, &pr, &lp) < 3) return false;
@@ -142,15 +193,17 @@ struct SceneOptions {
       tune = {a, b, c, dd, k8, db ? db : 65, mx, ln, pr, lp ? lp : 1};
       return true;
     }
+#endif
     return false;
   }
   void fromEnvironment() {
     static const char* const map[][2] = {{"MI_RAYLIB_FULL_STATS", "full_stats"}, {"MI_RAYLIB_KERNEL", "kernel"}, {"MI_RAYLIB_WAVES", "waves"}, {"MI_RAYLIB_SPEC", "spec"},
                                          {"MI_RAYLIB_SEG_BUDGET_KB", "seg_budget_kb"}, {"MI_RAYLIB_NIF_SPL", "nif_spl"}, {"MI_RAYLIB_PIN", "pin"},
                                          {"MI_RAYLIB_NIF_SHAPE", "nif_shape"}, {"MI_RAYLIB_TUNE", "tune"},
-                                         {"MI_RAYLIB_POOL_TUNE", "pool_tune"}, {"MI_RAYLIB_POOL_WAVES", "pool_waves"},
-                                         {"MI_RAYLIB_DOUBLE_FALLBACK", "double_fallback"}, {"MI_RAYLIB_FAST", "fast"}};
-    // (an unparsable environment value is ignored: the option keeps its default)
+                                         {"MI_RAYLIB_POOL_TUNE", "pool_tune"}, {"MI_RAYLIB_POOL_WAVES", "pool_waves"}, {"MI_RAYLIB_CUS", "cus"}};
+    // (an unparsable environment value is ignored: the option keeps its default. The two options that select ARITHMETIC,
+    // double_fallback and fast, are deliberately not in this list: a process that says "bit-exact" must not change tier
+    // because of a variable somebody exported)
     for (const auto& m : map) if (const char* e = getenv(m[0])) (void)set(m[1], e);
     if (getenv("MI_RAYLIB_NO_TILES")) tiles = false;
   }
@@ -165,7 +218,7 @@ struct LaunchSlot {
   hipStream_t stream = nullptr;
   uint32_t* d_workCounter = nullptr;
   float* d_segPart = nullptr; size_t segPartFloats = 0;     // [segments][n][3]
-  uint32_t* d_poolScratch = nullptr; size_t poolScratchWords = 0;   // kernel 3: [PG_WORDS][slots of the grid]
+  uint32_t* d_poolScratch = nullptr; size_t poolScratchWords = 0;   // kernel 3 (variants build): [PG_WORDS][slots of the grid]
 };
 
 struct mi_scene {
@@ -177,6 +230,17 @@ struct mi_scene {
   std::vector<void*> allocations;
   unsigned long long* d_counters = nullptr;
   std::vector<LaunchSlot> slots;
+  std::map<const void*, int> residentPerCU;      // workgroups of a kernel that stay resident on one compute unit (hipOccupancyMaxActiveBlocksPerMultiprocessor), asked once per kernel
+  uint32_t cus() const { return opt.cus ? opt.cus : (uint32_t)numCUs; }
+  uint32_t residentBlocks(const void* kern, int threads, size_t ldsBytes) {
+    auto it = residentPerCU.find(kern);
+    if (it == residentPerCU.end()) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, ldsBytes) != hipSuccess || nb <= 0) { (void)hipGetLastError(); nb = 8; }
+      it = residentPerCU.emplace(kern, nb).first;
+    }
+    return (uint32_t)it->second;
+  }
   bool poolAttrSet[2][3] = {{false, false, false}, {false, false, false}};
   bool ldsAttrSet[2] = {false, false};   // kernel 2's dynamic-LDS opt-in (plain / instrumented build), per scene and so per device: function attributes are per device
   hipEvent_t nifDone = nullptr; bool nifPending = false;
@@ -189,8 +253,16 @@ struct mi_scene {
   size_t rayBatch = 0;               // rays per mi_render batch (0 = the whole stream in one batch)
   NifDevice nif;
   // scratch for the per-sample NIF loop
-  Rng* d_rng = nullptr; float* d_u = nullptr; float* d_v = nullptr; float* d_bgr = nullptr; size_t scratchRays = 0;
-  float* d_slotColor = nullptr; float* d_slotTp = nullptr;   // NIF renders: per-(sample, pixel) slots of one launch
+  // NIF renders: per-(sample, pixel) slots of one launch. TWO sets, so that the trace launch of sample batch b + 1 (into the
+  // other set, on the render's stream) runs beside the MLP + accumulate pass of batch b (on nifAux): the MLP fills every CU
+  // but its workgroups come and go in generations, and the traversal kernel takes the gaps (launch ramps and tails).
+  struct NifSlots {
+    float* u = nullptr; float* v = nullptr; float* bgr = nullptr; float* color = nullptr; float* tp = nullptr;
+    uint32_t* index = nullptr; uint32_t* count = nullptr;
+    hipEvent_t traced = nullptr, done = nullptr; bool donePending = false;
+  } nifSlots[2];
+  hipStream_t nifAux = nullptr;
+  Rng* d_rng = nullptr; size_t scratchRays = 0;
   float* d_segTotal = nullptr;                                // sample-at-a-time NIF renders: sum of the finished segments, [n][3]
   uint32_t scratchSamples = 0;                                // samples per launch the slot buffers are sized for
   uint32_t scratchAsked = 0;                                  // the MI_RAYLIB_NIF_SPL value they were sized under (0 = default)
@@ -200,17 +272,22 @@ struct mi_scene {
     (void)hipSetDevice(device);
     for (void* p : allocations) (void)hipFree(p);
     if (d_rng) (void)hipFree(d_rng);
-    if (d_u) (void)hipFree(d_u);
-    if (d_v) (void)hipFree(d_v);
-    if (d_bgr) (void)hipFree(d_bgr);
-    if (d_slotColor) (void)hipFree(d_slotColor);
-    if (d_slotTp) (void)hipFree(d_slotTp);
+    freeNifSlots();
+    for (NifSlots& q : nifSlots) { if (q.count) (void)hipFree(q.count); if (q.traced) (void)hipEventDestroy(q.traced); if (q.done) (void)hipEventDestroy(q.done); }
+    if (nifAux) (void)hipStreamDestroy(nifAux);
     if (d_segTotal) (void)hipFree(d_segTotal);
     for (LaunchSlot& l : slots) { if (l.d_workCounter) (void)hipFree(l.d_workCounter); if (l.d_segPart) (void)hipFree(l.d_segPart); if (l.d_poolScratch) (void)hipFree(l.d_poolScratch); }
     for (int i = 0; i < 2; ++i) { if (d_batch[i]) (void)hipFree(d_batch[i]); if (pipeStream[i]) (void)hipStreamDestroy(pipeStream[i]); }
     if (nifDone) (void)hipEventDestroy(nifDone);
     for (auto& e : nifTimes) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     nif.release();
+  }
+  void freeNifSlots() {
+    for (NifSlots& q : nifSlots) {
+      for (float** p : {&q.u, &q.v, &q.bgr, &q.color, &q.tp}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+      if (q.index) (void)hipFree(q.index);
+      q.index = nullptr;
+    }
   }
   template <class T> T* keep(T* p) { if (p) allocations.push_back((void*)p); return p; }
   // the launch slot of a stream (created on first use; a scene is thread-compatible, not thread-safe)
@@ -391,28 +468,35 @@ void ensureScratch(mi_scene& S, size_t n) {
     if (!(asked >= 1 && asked <= 128))
       while (v > segLen && (uint64_t)n * v * 44u > ((uint64_t)16 << 30)) v -= segLen;
     // keep what is there when it still fits this stream and the request has not changed
-    if (S.scratchRays >= n && S.scratchAsked == asked && S.scratchSamples >= segLen && S.scratchSamples % segLen == 0) return;
+    const bool haveTwo = S.nifSlots[1].u != nullptr;
+    if (S.scratchRays >= n && S.scratchAsked == asked && S.scratchSamples >= segLen && S.scratchSamples % segLen == 0 &&
+        (haveTwo || !(S.opt.nifOverlap && S.ds.samplesPerPixel > S.scratchSamples))) return;
     S.scratchAsked = asked;
-    if (v != S.scratchSamples) { S.scratchSamples = v; S.scratchRays = 0; }     // slot buffers are sized for n x v
+    if (v != S.scratchSamples || (!haveTwo && S.opt.nifOverlap && S.ds.samplesPerPixel > v)) { S.scratchSamples = v; S.scratchRays = 0; }     // slot buffers are sized for n x v (x two sets)
   }
   if (S.scratchRays >= n) return;
   if (S.nifPending) { HIP_CHECK(hipDeviceSynchronize()); S.nifPending = false; }      // an earlier NIF render may still read the old buffers
   if (S.d_rng) (void)hipFree(S.d_rng);
-  if (S.d_u) (void)hipFree(S.d_u);
-  if (S.d_v) (void)hipFree(S.d_v);
-  if (S.d_bgr) (void)hipFree(S.d_bgr);
-  if (S.d_slotColor) (void)hipFree(S.d_slotColor);
-  if (S.d_slotTp) (void)hipFree(S.d_slotTp);
   if (S.d_segTotal) (void)hipFree(S.d_segTotal);
-  S.d_rng = nullptr; S.d_u = S.d_v = S.d_bgr = S.d_slotColor = S.d_slotTp = S.d_segTotal = nullptr; S.scratchRays = 0;
+  S.freeNifSlots();
+  S.d_rng = nullptr; S.d_segTotal = nullptr; S.scratchRays = 0;
   const size_t slots = n * S.scratchSamples;
   HIP_CHECK(hipMalloc(&S.d_rng, n * sizeof(Rng)));
-  HIP_CHECK(hipMalloc(&S.d_u, slots * sizeof(float)));
-  HIP_CHECK(hipMalloc(&S.d_v, slots * sizeof(float)));
-  HIP_CHECK(hipMalloc(&S.d_bgr, 3 * slots * sizeof(float)));
-  HIP_CHECK(hipMalloc(&S.d_slotColor, 3 * slots * sizeof(float)));
-  HIP_CHECK(hipMalloc(&S.d_slotTp, 3 * slots * sizeof(float)));
   HIP_CHECK(hipMalloc(&S.d_segTotal, 3 * n * sizeof(float)));
+  // the second set only where it is used: renders of more than one sample batch with the overlap on
+  const int sets = (S.opt.nifOverlap && S.ds.samplesPerPixel > S.scratchSamples) ? 2 : 1;
+  for (int k = 0; k < sets; ++k) {
+    mi_scene::NifSlots& q = S.nifSlots[k];
+    HIP_CHECK(hipMalloc(&q.u, slots * sizeof(float)));
+    HIP_CHECK(hipMalloc(&q.v, slots * sizeof(float)));
+    HIP_CHECK(hipMalloc(&q.bgr, 3 * slots * sizeof(float)));
+    HIP_CHECK(hipMalloc(&q.color, 3 * slots * sizeof(float)));
+    HIP_CHECK(hipMalloc(&q.tp, 3 * slots * sizeof(float)));
+    HIP_CHECK(hipMalloc(&q.index, slots * sizeof(uint32_t)));
+    if (!q.count) HIP_CHECK(hipMalloc(&q.count, sizeof(uint32_t)));
+    if (!q.traced) HIP_CHECK(hipEventCreateWithFlags(&q.traced, hipEventDisableTiming));
+    if (!q.done) HIP_CHECK(hipEventCreateWithFlags(&q.done, hipEventDisableTiming));
+  }
   S.scratchRays = n;
 }
 
@@ -463,19 +547,28 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
     HIP_CHECK(hipMemsetAsync(workCounter, 0, sizeof(uint32_t), stream));
     const uint64_t items = (uint64_t)cnt * ((segmented || !plain) ? exs.segments : 1u);     // work atoms of this launch
     if (items > kMaxWorkItems) throw ArgError("mi_render: too many work items for one launch (cut the stream with mi_scene_set_ray_batch)");
+    // Grid: persistent workgroups, as many as stay resident (compute units x workgroups per unit, asked of the runtime for
+    // the kernel about to be launched and remembered per scene), never more than the launch has work for.
+    auto grid = [&](auto kern, uint32_t threads, size_t ldsBytes) {
+      return (uint32_t)std::min<uint64_t>((items + threads - 1) / threads, (uint64_t)S.cus() * S.residentBlocks(reinterpret_cast<const void*>(kern), (int)threads, ldsBytes));
+    };
+    auto go = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3(grid(kern, 256, 0)), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
+    };
     if (S.opt.doubleFallback) {
       // the ALLOW_DOUBLE_FALLBACK=1 variant: the phase-scheduled kernel's 4-wave build with the binary64 edge functions compiled in
-      const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 255) / 256, 256 * 8);
-      hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, 4, false, 2, false, true>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
-    } else if (S.opt.fast && plain && !STATS) {
-      // the tolerance tier (never the default): FMA box and triangle tests
-      const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 255) / 256, 256 * 8);
-      hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, 5, false, 0, true, false, true>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
+      go(path_trace_wavefront_kernel<STATS, false, 256, 4, false, 2, false, true>);
+    } else if (S.opt.fast) {
+      // the tolerance tier (never the default): FMA box and triangle tests. Plain, un-instrumented launches of the default kernel only;
+      // mi_scene_set_option refuses the combinations it has no build for, a NIF render is refused here.
+      if (!plain || STATS) throw ArgError("mi_render: the tolerance tier (option fast) has no NIF / instrumented build; clear the option for this render");
+      go(path_trace_wavefront_kernel<false, false, 256, 5, false, 0, true, false, true>);
+#if MI_RAYLIB_VARIANTS
     } else if (S.opt.kernelChoice == 3 && S.ds.samplesPerPixel <= kPoolMaxSamples && S.ds.maxPathLength <= kPoolMaxBounces) {
       // path pool (trace_pool.hpp): persistent, exactly as many workgroups as stay resident; a workgroup of W waves
       // owns 100 W path slots
       const uint32_t W = (uint32_t)S.opt.poolWaves, pwg = 100u * W;
-      const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + pwg - 1) / pwg, (uint64_t)S.numCUs * (16u / W));
+      const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + pwg - 1) / pwg, (uint64_t)S.cus() * (16u / W));
       const uint32_t stride = blocks * pwg;
       const size_t need = (size_t)PG_WORDS * stride;
       if (slot.poolScratchWords < need) {
@@ -485,16 +578,16 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
         slot.poolScratchWords = need;
       }
       const size_t ldsBytes = pool_lds_bytes(pwg);
-      auto go = [&](auto kern, int which) {
+      auto goPool = [&](auto kern, int which) {
         if (!S.poolAttrSet[STATS ? 1 : 0][which]) {
           HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
           S.poolAttrSet[STATS ? 1 : 0][which] = true;
         }
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * W), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, S.opt.poolTune, tileW, exs, slot.d_poolScratch, stride);
       };
-      if (W == 4) go(path_trace_pool_kernel<STATS, 4, 400, 4>, 0);
-      else if (W == 8) go(path_trace_pool_kernel<STATS, 8, 800, 4>, 1);
-      else go(path_trace_pool_kernel<STATS, 16, 1600, 4>, 2);
+      if (W == 4) goPool(path_trace_pool_kernel<STATS, 4, 400, 4>, 0);
+      else if (W == 8) goPool(path_trace_pool_kernel<STATS, 8, 800, 4>, 1);
+      else goPool(path_trace_pool_kernel<STATS, 16, 1600, 4>, 2);
     } else if (plain && S.opt.kernelChoice == 2 && S.ds.numNodes > 0) {
       // one 1024-thread workgroup per CU shares one LDS copy of the first nodes of the (preorder) array
       const uint32_t ldsNodes = std::min<uint32_t>(S.ds.numNodes, kLdsBudgetBytes / (uint32_t)sizeof(GNode));
@@ -504,20 +597,21 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudgetBytes));
         S.ldsAttrSet[STATS ? 1 : 0] = true;
       }
-      const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 1023) / 1024, 256);
+      const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 1023) / 1024, S.cus());
       hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, ldsNodes, S.opt.tune, tileW, exs);
+    } else if (S.opt.specLeaf) {
+      if (!STATS && S.opt.wavesPerSimd == 5) go(path_trace_wavefront_kernel<false, false, 256, 5, true>);
+      else go(path_trace_wavefront_kernel<STATS, false, 256, 4, true>);
+    } else if (!STATS && S.opt.wavesPerSimd == 5 && !(S.opt.tune == kDefaultTune)) {
+      go(path_trace_wavefront_kernel<false, false, 256, 5>);            // runtime weights (tune sweeps): 42 scalar spills, 4 % slower
+#endif
     } else if (!STATS && S.opt.wavesPerSimd == 5) {
-      // 96-VGPR build: 5 waves per SIMD (+4.6 % on the box scene; 6 waves = 80 VGPRs: -19 %, its spills land in LEAF/SHADE)
-      const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 255) / 256, 256 * 8);
-      const bool fixed = S.opt.tune == kDefaultTune;      // the default weights are compiled into the two default-path instantiations
-      if (S.opt.specLeaf) hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, 5, true>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
-      else if (fixed && plain) hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, 5, false, 0, true>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
-      else if (fixed) hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, 5, false, 1, true>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
-      else hipLaunchKernelGGL((path_trace_wavefront_kernel<false, false, 256, 5>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
+      // the default path. 96-VGPR build, 5 waves per SIMD (+4.6 % on the box scene; 6 waves = 80 VGPRs: -19 %, its spills land
+      // in LEAF/SHADE); the default scheduling weights are compiled into the two instantiations (plain renders / NIF slots)
+      if (plain) go(path_trace_wavefront_kernel<false, false, 256, 5, false, 0, true>);
+      else go(path_trace_wavefront_kernel<false, false, 256, 5, false, 1, true>);
     } else {
-      const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 255) / 256, 256 * 8);
-      if (S.opt.specLeaf) hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256, 4, true>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
-      else hipLaunchKernelGGL((path_trace_wavefront_kernel<STATS, false, 256>), dim3(blocks), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
+      go(path_trace_wavefront_kernel<STATS, false, 256>);               // the instrumented build (and, in the variants build, option waves = 4)
     }
     if (segmented) hipLaunchKernelGGL(segment_combine_kernel, dim3((cnt + 255) / 256), dim3(256), 0, stream, d_rays, cnt, exs.segments, slot.d_segPart, segBase ? 1u : 0u);
   }
@@ -557,23 +651,36 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
         // persistent phase-scheduled kernel, several samples per launch; every path leaves a slot (WaveExtras), the
         // MLP runs on the compacted escaped slots, and a per-pixel pass adds everything in the reference's order
         if ((uint64_t)cnt * S.scratchSamples > kMaxWorkItems) throw ArgError("mi_render: ray batch too large for a NIF render (cut it with mi_scene_set_ray_batch)");
-        S.nif.ensureIndex((size_t)cnt * S.scratchSamples);
         const uint32_t segLen = segment_samples(S.ds.samplesPerPixel), segShift = segment_shift(S.ds.samplesPerPixel);
-        for (uint32_t s0 = 0; s0 < S.ds.samplesPerPixel; s0 += S.scratchSamples) {
+        // Sample batch b: trace its slots on `stream` (set b & 1), then MLP over the compacted escaped slots + the accumulate
+        // pass - on nifAux when there are two sets, so that the trace launch of batch b + 1 runs beside them. The accumulate
+        // passes run in batch order on one stream and touch only rgb; the trace launch only reads the pixel coordinates and
+        // writes the hit record of the same TraceResults (other dwords), so the two never meet. A set is traced into again
+        // only when the MLP + accumulate that read it are done; the render's stream ends behind the last of them.
+        const bool two = S.opt.nifOverlap && S.nifSlots[1].u != nullptr;
+        if (two && !S.nifAux) HIP_CHECK(hipStreamCreateWithFlags(&S.nifAux, hipStreamNonBlocking));
+        hipStream_t mlpStream = two ? S.nifAux : stream;
+        uint32_t b = 0;
+        for (uint32_t s0 = 0; s0 < S.ds.samplesPerPixel; s0 += S.scratchSamples, ++b) {
+          mi_scene::NifSlots& q = S.nifSlots[two ? (b & 1u) : 0u];
           const uint32_t sc = std::min<uint32_t>(S.scratchSamples, S.ds.samplesPerPixel - s0);
-          HIP_CHECK(hipMemsetAsync(S.nif.d_count, 0, sizeof(uint32_t), stream));
+          if (two && q.donePending) { HIP_CHECK(hipStreamWaitEvent(stream, q.done, 0)); q.donePending = false; }
+          HIP_CHECK(hipMemsetAsync(q.count, 0, sizeof(uint32_t), stream));
           WaveExtras ex;
           ex.sampleCount = sc; ex.segments = (sc + segLen - 1) / segLen; ex.segBase = s0 / segLen;     // (pixel, segment) atoms
-          ex.u = S.d_u; ex.v = S.d_v; ex.slotColor = S.d_slotColor; ex.slotTp = S.d_slotTp;
-          ex.index = S.nif.d_index; ex.count = S.nif.d_count; ex.azimuthRotation = radians;
+          ex.u = q.u; ex.v = q.v; ex.slotColor = q.color; ex.slotTp = q.tp;
+          ex.index = q.index; ex.count = q.count; ex.azimuthRotation = radians;
           if (S.opt.fullStats) launchWavefront<true>(S, d_rays, cnt, stream, ex);
           else launchWavefront<false>(S, d_rays, cnt, stream, ex);
+          if (two) { HIP_CHECK(hipEventRecord(q.traced, stream)); HIP_CHECK(hipStreamWaitEvent(mlpStream, q.traced, 0)); }
           std::pair<hipEvent_t, hipEvent_t> tm{nullptr, nullptr};
-          if (S.opt.nifTiming) { HIP_CHECK(hipEventCreate(&tm.first)); HIP_CHECK(hipEventCreate(&tm.second)); S.nifTimes.push_back(tm); HIP_CHECK(hipEventRecord(tm.first, stream)); }
-          nif_launch_mlp(S.nif, S.d_u, S.d_v, S.nif.d_index, S.nif.d_count, cnt * sc, S.d_bgr, nullptr, stream, true, S.opt.nifShape);
-          if (tm.second) HIP_CHECK(hipEventRecord(tm.second, stream));
-          hipLaunchKernelGGL(nif_accumulate_kernel, grid, block, 0, stream, d_rays, cnt, sc, segShift, ex.segBase, S.d_slotColor, S.d_slotTp, S.d_u, S.d_bgr);
+          if (S.opt.nifTiming) { HIP_CHECK(hipEventCreate(&tm.first)); HIP_CHECK(hipEventCreate(&tm.second)); S.nifTimes.push_back(tm); HIP_CHECK(hipEventRecord(tm.first, mlpStream)); }
+          nif_launch_mlp(S.nif, q.u, q.v, q.index, q.count, cnt * sc, q.bgr, nullptr, mlpStream, true, S.opt.nifShape, S.cus());
+          if (tm.second) HIP_CHECK(hipEventRecord(tm.second, mlpStream));
+          hipLaunchKernelGGL(nif_accumulate_kernel, grid, block, 0, mlpStream, d_rays, cnt, sc, segShift, ex.segBase, q.color, q.tp, q.u, q.bgr);
+          if (two) { HIP_CHECK(hipEventRecord(q.done, mlpStream)); q.donePending = true; }
         }
+        if (two) for (mi_scene::NifSlots& q : S.nifSlots) if (q.donePending) { HIP_CHECK(hipStreamWaitEvent(stream, q.done, 0)); q.donePending = false; }
       } else {
         const uint32_t segLen = segment_samples(S.ds.samplesPerPixel);
         for (uint32_t s = 0; s < S.ds.samplesPerPixel; ++s) {
@@ -581,7 +688,7 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
           if (s != 0 && s % segLen == 0) hipLaunchKernelGGL(nif_segment_roll_kernel, grid, block, 0, stream, d_rays, S.d_segTotal, cnt, s / segLen, 0u);
           if (S.opt.fullStats) hipLaunchKernelGGL(path_trace_kernel<true>, grid, block, 0, stream, S.ds, d_rays, cnt, s, 1u, S.d_rng);
           else hipLaunchKernelGGL(path_trace_kernel<false>, grid, block, 0, stream, S.ds, d_rays, cnt, s, 1u, S.d_rng);
-          nif_env_pass(S.nif, d_rays, cnt, radians, S.d_u, S.d_v, S.d_bgr, S.maxNifBatch, stream, S.opt.nifShape);
+          nif_env_pass(S.nif, d_rays, cnt, radians, S.nifSlots[0].u, S.nifSlots[0].v, S.nifSlots[0].bgr, S.maxNifBatch, stream, S.opt.nifShape, S.cus());
         }
         if (S.ds.samplesPerPixel > segLen) hipLaunchKernelGGL(nif_segment_roll_kernel, grid, block, 0, stream, d_rays, S.d_segTotal, cnt, 0u, 1u);
       }
@@ -600,7 +707,13 @@ extern "C" {
 
 const char* mi_last_error(void) { return g_err.c_str(); }
 
-const char* mi_version(void) { return "mi_raylib 0.1 gfx950 fp-contract=off (bit-exact to the reference CPU path)"; }
+const char* mi_version(void) {
+#if MI_RAYLIB_VARIANTS
+  return "mi_raylib 0.1 gfx950 fp-contract=off (bit-exact to the reference CPU path) +variants";
+#else
+  return "mi_raylib 0.1 gfx950 fp-contract=off (bit-exact to the reference CPU path)";
+#endif
+}
 
 int mi_scene_create(const mi_scene_desc* desc, mi_scene** out) {
   if (!desc || !out) { g_err = "mi_scene_create: null argument"; return MI_ERR_INVALID_ARG; }
@@ -722,7 +835,7 @@ int mi_render(mi_scene* scene, int mode, mi_trace_result* rays, size_t n, mi_ray
 
 int mi_scene_set_option(mi_scene* scene, const char* key, const char* value) {
   if (!scene || !key || !value) { g_err = "mi_scene_set_option: null argument"; return MI_ERR_INVALID_ARG; }
-  if (!scene->opt.set(key, value)) { g_err = std::string("mi_scene_set_option: unknown option or bad value: ") + key + "=" + value; return MI_ERR_INVALID_ARG; }
+  if (!scene->opt.set(key, value)) { g_err = std::string("mi_scene_set_option: ") + scene->opt.why + ": " + key + "=" + value; return MI_ERR_INVALID_ARG; }
   return MI_OK;
 }
 
@@ -750,7 +863,7 @@ int mi_get_phase_stats(mi_scene* scene, uint64_t stats[12]) {
   });
 }
 
-int mi_get_pool_stats(mi_scene* scene, uint64_t stats[8]) {
+int mi_get_pool_stats(mi_scene* scene, uint64_t stats[8]) {      // (zeros in a library built without the path-pool kernel)
   if (!scene || !stats) { g_err = "mi_get_pool_stats: null argument"; return MI_ERR_INVALID_ARG; }
   return guarded([&] {
     HIP_CHECK(hipSetDevice(scene->device));
@@ -819,7 +932,7 @@ int mi_nif_infer_device(mi_scene* scene, const float* d_u, const float* d_v, flo
   if (!scene->nif.loaded()) { g_err = "mi_nif_infer_device: no NIF model loaded"; return MI_ERR_NO_NIF; }
   return guarded([&] {
     HIP_CHECK(hipSetDevice(scene->device));
-    nif_infer(scene->nif, d_u, d_v, d_bgr, n, scene->maxNifBatch, (hipStream_t)hip_stream, scene->opt.nifShape);
+    nif_infer(scene->nif, d_u, d_v, d_bgr, n, scene->maxNifBatch, (hipStream_t)hip_stream, scene->opt.nifShape, scene->cus());
     HIP_CHECK(hipGetLastError());
   });
 }

@@ -81,6 +81,20 @@ struct WaveExtras {
 // from ex.slotColor. FIXED_TUNE: the scheduling weights are the compile-time defaults (kDefaultTune) instead of the
 // `tune` argument. The two default-path instantiations (<.., 0, true> and <.., 1, true>) carry neither the other mode's
 // code nor the ten weights in scalar registers: no scalar spills (33 before), -2.5 % frame time.
+// FAST tier, per cast: the constant terms of the box test's FMAs (-o/d) and the pad of its far side. An axis the ray runs
+// parallel to (v_rcp_f32 of a zero component: infinite) would make them inf - inf = NaN, and every box would then read as
+// hit (fminf / fmaxf drop a NaN): correct, but such a ray walked the whole BVH. A large finite stand-in for 1/d gives what
+// the slab test means for a parallel ray - no constraint when the origin lies between the planes (-huge, +huge), a miss
+// otherwise - through the same FMAs, and that axis is left out of the pad (its cancellation error is beside the point: the
+// products are huge either way). The shear keeps the true reciprocal (make_shear_fast is called before this).
+__device__ __forceinline__ void fast_box_setup(f3 o, f3& inv, f3& oi, float& slabPad) {
+  const float big = 1e18f;
+  const bool px = !(fabsf(inv.x) < big), py = !(fabsf(inv.y) < big), pz = !(fabsf(inv.z) < big);
+  inv = mk(px ? copysignf(big, inv.x) : inv.x, py ? copysignf(big, inv.y) : inv.y, pz ? copysignf(big, inv.z) : inv.z);
+  oi = mk(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
+  slabPad = 4.8e-7f * fmaxf(fmaxf(px ? 0.f : fabsf(oi.x), py ? 0.f : fabsf(oi.y)), pz ? 0.f : fabsf(oi.z));
+}
+
 constexpr WaveTune kDefaultTune = {8, 16, 24, 48, 3, 4, 6, 1, 1, 40};      // re-swept on the round-3 kernel on two scenes (profiles/r03_kernel_ab.txt): a cheaper box test favours one more of them per vote
 // DF: the reference's ALLOW_DOUBLE_FALLBACK=1 build of the triangle test (trace_kernels.hpp). FAST: the tolerance tier
 // (scene option "fast"): the box test as three pairs of FMAs on (plane, 1/d, -o/d), the triangle test contracted, no
@@ -126,7 +140,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
 
   // ---- lane state ----
   uint32_t ph = PH_FETCH;
-  uint32_t pix = 0, sample = 0, bounce = 0, node = 0, pendLeaf = 0;
+  uint32_t sample = 0, bounce = 0, node = 0, pendLeaf = 0;
   uint32_t pend1 = 0xFFFFFFFFu, pend1Node = 0, specNodes = 0;       // SPEC: the primitive test the lane has walked past, where it was found, box tests made since (STATS)
   float prow = 0.f, pcol = 0.f;
   Rng rng; rng.s0 = rng.s1 = 0;
@@ -196,7 +210,6 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
             const uint32_t t = pidx >> 6, within = pidx & 63u, perRow = tileStreamW >> 3;
             entry = ((t / perRow) * 8u + (within >> 3)) * tileStreamW + (t % perRow) * 8u + (within & 7u);
           }
-          pix = entry;
           const mi_trace_result* res = rays + entry;
           prow = res->u; pcol = res->v;
           coldU(0) = entry; coldF(1) = prow; coldF(2) = pcol;
@@ -532,7 +545,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
             exactSlab = !(fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf && fabsf(o.x) < kInf && fabsf(o.y) < kInf && fabsf(o.z) < kInf);
             sh = make_shear(d, inv);
           }
-          if (FAST) { oi = mk(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z)); slabPad = 4.8e-7f * fmaxf(fmaxf(fabsf(oi.x), fabsf(oi.y)), fabsf(oi.z)); }
+          if (FAST) fast_box_setup(o, inv, oi, slabPad);
           hit.t = kInf; hit.leaf = 0xFFFFFFFFu;
           { uint32_t seen; node = root_start(sc, o, seen) << 5; if (STATS) cs.nodes += seen; }
           ++casts;
@@ -589,7 +602,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
           exactSlab = !(fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf && fabsf(o.x) < kInf && fabsf(o.y) < kInf && fabsf(o.z) < kInf);
           sh = make_shear(d, inv);
         }
-        if (FAST) { oi = mk(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z)); slabPad = 4.8e-7f * fmaxf(fmaxf(fabsf(oi.x), fabsf(oi.y)), fabsf(oi.z)); }
+        if (FAST) fast_box_setup(o, inv, oi, slabPad);
         hit.t = kInf; hit.leaf = 0xFFFFFFFFu;
         { uint32_t seen; node = root_start(sc, o, seen) << 5; if (STATS) cs.nodes += seen; }
         ++casts;

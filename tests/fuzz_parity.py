@@ -134,7 +134,7 @@ def nif_campaign(budget, seed, max_cases=None, replay_case=None):
                 f"roulette={d.roulette_start_depth} mlp={layers}x{hidden} spl={spl or 'default'} rot={rot:.2f}")
 
         def render(kernel):
-            dev = irl.IpuScene(d).set_option("kernel", kernel)
+            dev = irl.IpuScene(d, variants=kernel not in ("0", "1")).set_option("kernel", kernel)      # (kernel 3 lives in the variants build)
             if spl:
                 dev.set_option("nif_spl", spl)
             dev.setNif(ks, bs, relu, 12, 3.43, np.array([-2.35, -2.26, -1.96], np.float32), True)
@@ -206,7 +206,11 @@ def campaign(budget=240.0, seed=1, scale=1, max_cases=None):
         df = int(rng.random() < 0.2)          # the reference's ALLOW_DOUBLE_FALLBACK=1 build, on both sides (Mesh.cpp:38-51)
         desc = (f"case {case} (seed {seed}): {what} {w}x{h} crop={crop} spp={spp} rngseed={d.rng_seed} aa={d.anti_alias_scale} "
                 f"len={d.max_path_length} roulette={d.roulette_start_depth} mode={mode} kernel={kernel} waves={waves} batch={batch} double_fallback={df}")
-        dev = irl.IpuScene(d).set_option("kernel", kernel).set_option("waves", waves).set_option("spec", int(rng.integers(0, 2))).set_option("double_fallback", df)
+        spec = int(rng.integers(0, 2))
+        # the shipped library when the case draws its default path (or the nested-loop kernel), the variants build of the same
+        # sources otherwise: both are under the campaign
+        use_variants = kernel not in ("0", "1") or waves != "5" or spec == 1
+        dev = irl.IpuScene(d, variants=use_variants).set_option("kernel", kernel).set_option("waves", waves).set_option("spec", spec).set_option("double_fallback", df)
         got = s.init_ray_stream()
         if rng.random() < 0.3:
             for k in "xyz":

@@ -4,6 +4,7 @@ BIT: the device library is built with -ffp-contract=off and the hot path uses on
 IEEE operations (+ - * / sqrt), so there is no tolerance to state — except for the NIF MLP, whose
 tolerance is written in its test.
 """
+import contextlib
 import ctypes as C
 from pathlib import Path
 
@@ -27,6 +28,16 @@ def assert_streams_identical(got, want, what):
     if bad.size:
         i = int(bad[0])
         raise AssertionError(f"{what}: {bad.size}/{got.size} TraceResults differ; first at {i}:\n got  {got[i]}\n want {want[i]}")
+
+
+@contextlib.contextmanager
+def _desc_restored(d):
+    """The built-in scenes' descs are shared by the module's tests: whatever a test does to one is undone, pass or fail."""
+    saved = bytes(d)
+    try:
+        yield d
+    finally:
+        C.memmove(C.byref(d), saved, len(saved))
 
 
 @pytest.fixture(scope="module")
@@ -65,7 +76,7 @@ def test_traversal_visits_exactly_the_reference_nodes(scenes, spec):
     s = scenes["box"]
     s.desc.set_image(256, 256)
     s.desc.samples_per_pixel = 3
-    dev = irl.IpuScene(s.desc).set_option("full_stats", 1).set_option("spec", spec)
+    dev = irl.IpuScene(s.desc, variants=bool(spec)).set_option("full_stats", 1).set_option("spec", spec)
     got = s.init_ray_stream(); want = got.copy()
     dev.run(got, irl.MODE_SHADOW_TRACE)
     st = ol.shadow_trace(s.desc, want, 16)
@@ -84,6 +95,15 @@ def test_traversal_visits_exactly_the_reference_nodes(scenes, spec):
 # ------------------------------------------------------------------------------------------------------
 # path trace: rgb sums + last-sample hit records, per-pixel RNG streams
 # ------------------------------------------------------------------------------------------------------
+def _needs_variants(kernel):
+    """Kernels 0 and 1 are in the shipped library; everything else lives in the variants build (libmi_raylib_variants.so)."""
+    return kernel not in ("0", "1")
+
+
+def _scene_with_kernel(desc, kernel):
+    return _with_kernel(irl.IpuScene(desc, variants=_needs_variants(kernel)), kernel)
+
+
 def _with_kernel(dev, kernel):
     """kernel strings: "0" | "1" | "1w4" | "1s" (speculative walk past a pending primitive test) | "2" | "3" | "3p8" | "3p16" (variant + waves per SIMD / waves per pool workgroup)"""
     dev.set_option("kernel", kernel[0])
@@ -106,7 +126,7 @@ def test_path_trace_bit_exact(scenes, name, size, spp, kernel):
     s.desc.set_image(size, size)
     s.desc.path_trace = 1
     s.desc.samples_per_pixel = spp
-    dev = _with_kernel(irl.IpuScene(s.desc), kernel)
+    dev = _scene_with_kernel(s.desc, kernel)
     got = s.init_ray_stream(); want = got.copy()
     dev.run(got, irl.MODE_PATH_TRACE)
     st = ol.path_trace_pixel_rng(s.desc, want, 16)
@@ -431,9 +451,10 @@ def _nif_weights(rng, hidden=320, embed=12, layers=6):
     return ks, bs, relu
 
 
-@pytest.mark.parametrize("shape", ["w6", "t4", "t6"])
+@pytest.mark.parametrize("shape", ["w6", "t4", "t6", "r8", "r8s"])
 def test_nif_mlp_against_oracle(scenes, shape):
-    """(every workgroup shape of the kernel: w6 is the default, the others are selectable)
+    """(both MLP kernels: w6 (the default) / t4 / t6 are the workgroup shapes of nif_mlp_kernel; r8 / r8s name K3r, the
+    register-resident kernel of nif_regs_kernel.hpp - measured slower, kept selectable - with its waves in lock-step / staggered)
     MFMA MLP vs the oracle's fp16-rounded-inputs / fp32-accumulate restatement. Tolerance: the decoded
     (exp'd) radiance must agree to 2% relative + 1e-3 absolute for 99.9% of samples and 10% for all — fp32
     accumulation ORDER differs (MFMA 32-wide k blocks vs sequential), activations are re-rounded to binary16
@@ -463,9 +484,12 @@ def test_nif_mlp_against_oracle(scenes, shape):
     dev.close()
 
 
-@pytest.mark.parametrize("hidden,layers", [(32, 2), (64, 3), (96, 2), (160, 5), (224, 3), (256, 4), (320, 3), (352, 3), (384, 2)])
-def test_nif_mlp_shapes_against_oracle(scenes, hidden, layers):
-    """The MLP kernel's layer runs over networks of other shapes than the reference's: 1...6 output-feature tiles per
+@pytest.mark.parametrize("hidden,layers", [(32, 2), (64, 3), (96, 2), (128, 6), (160, 5), (224, 3), (256, 4), (320, 3), (352, 3), (384, 2)])
+@pytest.mark.parametrize("kernel", ["w6", "r8"])
+def test_nif_mlp_shapes_against_oracle(scenes, hidden, layers, kernel):
+    """(kernel r8: hidden widths 64, 128, 256 and 320 take K3r - nif_regs_kernel.hpp: 2, 4, 8 and 10 k-steps per layer, first,
+    plain and concat layers, a linear hidden layer, a layer without bias; for the other widths the option falls back to w6)
+    The MLP kernel's layer runs over networks of other shapes than the reference's: 1...6 output-feature tiles per
     wave (352 and 384 take the 8-wave fallback shape), every remainder of the k-step count against the k-loop's
     three-fold unrolling (first layer 2 k-steps; hidden / concat layers 1, 3, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14), a
     hidden layer without ReLU and one without bias. Same tolerance as test_nif_mlp_against_oracle."""
@@ -477,7 +501,7 @@ def test_nif_mlp_shapes_against_oracle(scenes, hidden, layers):
     mean = np.array([-2.35, -2.27, -1.96], np.float32)
     maxv = 3.43
     s = scenes["spheres"]
-    dev = irl.IpuScene(s.desc)
+    dev = irl.IpuScene(s.desc).set_option("nif_shape", kernel)
     dev.setNif(ks, bs, relu, 12, maxv, mean, True)
     n = 3000 + 53
     u = rng.random(n).astype(np.float32); v = rng.random(n).astype(np.float32)
@@ -640,7 +664,7 @@ def test_nif_render_sample_batching_is_order_exact(scenes, spl, spp):
     d.samples_per_pixel = spp; d.path_trace = 1
 
     def render(kernel):
-        dev = irl.IpuScene(d).set_option("kernel", kernel).set_option("nif_spl", spl)
+        dev = irl.IpuScene(d, variants=_needs_variants(kernel)).set_option("kernel", kernel).set_option("nif_spl", spl)
         dev.setNif(ks, bs, relu, 12, 3.43, mean, True)
         dev.setHdriRotation(12.5)
         rays = s.init_ray_stream()
@@ -697,7 +721,7 @@ def test_segmented_pixels_bit_exact(scenes, kernel, spp):
     for bit; so must a batched render (both pipeline slots, each with its own partial-sum buffer)."""
     s = scenes["box"]; d = s.desc
     d.set_image(72, 40); d.samples_per_pixel = spp; d.path_trace = 1
-    dev = _with_kernel(irl.IpuScene(d), kernel)
+    dev = _scene_with_kernel(d, kernel)
     got = s.init_ray_stream()
     rng = np.random.default_rng(3)
     for k in "xyz":
@@ -737,7 +761,7 @@ def _subsample_check(s, dev, stride, what, threads=16):
 def test_config2_headline_frame_1440_x_1000spp_against_oracle(scenes):
     """BASELINE config 2, the frame bench.py times: box scene, 1440x1440 x 1000 spp (sixteen segments per pixel, the
     last of 40 samples; 0.4 GB of partial sums; segment_combine_kernel). Every 509th pixel (4 074 pixels, all 84
-    bytes) against the oracle at the full 1000 spp, plus whole-frame sanity."""
+    bytes) against the oracle at the full 1000 spp, plus whole-frame sanity; then tier 2 on a window of the same frame."""
     s = scenes["box"]; d = s.desc
     d.set_image(1440, 1440); d.samples_per_pixel = 1000; d.path_trace = 1
     dev = irl.IpuScene(d)
@@ -748,6 +772,29 @@ def test_config2_headline_frame_1440_x_1000spp_against_oracle(scenes):
     rgb = np.stack([got["rgb"][k] for k in "xyz"], 1) / 1000.0
     assert np.isfinite(rgb).all() and 0.05 < rgb.mean() < 5.0
     dev.close()
+    # Tier 2 AT THE HEADLINE SIZE (the reference's own acceptance method, LITERATE_TEST.ipynb cells 18-19; trace.cpp:236-256):
+    # a 96 x 96 window of this very frame against the oracle's literal restatement of renderCPU - ONE shared generator consumed
+    # sequentially, libstdc++ normal_distribution jitter - over the same window of the 1440 x 1440 image at 1000 spp. Different
+    # random numbers, same estimator: channel means within the Monte-Carlo bound, cross-scheme MSE = seed-to-seed MSE.
+    c0, r0, n = 672, 640, 96                       # (mirror sphere, glass monkey and the lit back wall meet here)
+    win = np.ascontiguousarray(got.reshape(1440, 1440)[r0:r0 + n, c0:c0 + n]).reshape(-1)
+    d.set_image(1440, 1440, (n, n, c0, r0))
+    imgs = {}
+    for seed in (1442, 99):
+        d.rng_seed = seed
+        dv = irl.IpuScene(d)
+        r = s.init_ray_stream(); dv.run(r, irl.MODE_PATH_TRACE); dv.close()
+        imgs[seed] = r
+    d.rng_seed = 1442
+    assert_streams_identical(imgs[1442], win, "the crop window rendered on its own against the same window of the full frame")
+    ref = s.init_ray_stream(); ol.path_trace_shared_rng(d, ref)
+    to_img = lambda a: np.stack([a["rgb"][k] for k in "xyz"], 1) / 1000.0
+    a, b, c = to_img(win), to_img(imgs[99]), to_img(ref)
+    # one 64 x 64 x 1000-spp render's channel means carry a relative sigma of about 0.9 % (test_gpu_image_against_the_literal_
+    # renderCPU_statistically); 2.25 x the samples here: 4 sigma of a difference of two such means
+    assert np.allclose(a.mean(0), c.mean(0), rtol=0.025), (a.mean(0), c.mean(0))
+    cross = np.mean((a - c) ** 2); same = np.mean((a - b) ** 2)
+    assert 0.5 < cross / same < 2.0, (cross, same)
     d.set_image(96, 64); d.samples_per_pixel = 5
 
 
@@ -890,7 +937,7 @@ def test_scene_options_are_per_scene(scenes, monkeypatch):
     plain = irl.IpuScene(d)
     probe = irl.IpuScene(d).set_option("full_stats", 1).set_option("kernel", 0)     # created AFTER `plain`
     monkeypatch.setenv("MI_RAYLIB_FULL_STATS", "1")                                 # the environment is read at create time only ...
-    other = irl.IpuScene(d).set_option("kernel", 2)
+    other = irl.IpuScene(d, variants=True).set_option("kernel", 2)       # (the variants build of the same sources, loaded beside the shipped library)
     monkeypatch.delenv("MI_RAYLIB_FULL_STATS")
     for dev, counted in ((plain, False), (probe, True), (other, True), (plain, False)):
         dev.reset_counters()
@@ -902,7 +949,43 @@ def test_scene_options_are_per_scene(scenes, monkeypatch):
         assert (c["nodes_visited"] == st.nodesVisited) if counted else (c["nodes_visited"] == 0)
     with pytest.raises(irl.RaylibError, match="unknown option"):
         plain.set_option("no_such_option", 1)
+    # the shipped library carries the default path only: the measured-and-rejected kernel families are refused by name
+    for key, value in (("kernel", 2), ("kernel", 3), ("spec", 1), ("waves", 4), ("tune", "8,16,24"), ("pool_waves", 8)):
+        with pytest.raises(irl.RaylibError, match="not compiled into this library"):
+            plain.set_option(key, value)
+    plain.set_option("kernel", 1).set_option("spec", 0).set_option("waves", 5)      # the defaults are accepted
+    assert b"+variants" in irl.device_lib(True).mi_version() and b"+variants" not in irl.device_lib().mi_version()
     plain.close(); probe.close(); other.close()
+
+
+def test_launch_grids_follow_the_compute_unit_count(scenes):
+    """Launch grids are compute units x workgroups resident per unit (hipOccupancyMaxActiveBlocksPerMultiprocessor, asked
+    per kernel), not a literal: option "cus" stands in for a device with another unit count (a partitioned MI355X shows
+    32 or 64). With 16 and with 1 000 units the persistent kernels hand out the same work items from the same counter and
+    the MLP's grid-stride loop covers the same rows: every TraceResult byte stays what it was - plain render against the
+    oracle, NIF render against the default grid's."""
+    s = scenes["box"]
+    with _desc_restored(s.desc) as d:
+        d.set_image(200, 120); d.samples_per_pixel = 70; d.path_trace = 1
+        want = s.init_ray_stream(); ol.path_trace_pixel_rng(d, want, 16)
+        for cus in (16, 1000, 0):
+            dev = irl.IpuScene(d).set_option("cus", cus)
+            got = s.init_ray_stream(); dev.run(got, irl.MODE_PATH_TRACE); dev.close()
+            assert_streams_identical(got, want, f"plain render on a grid for {cus} compute units")
+        with pytest.raises(irl.RaylibError):
+            irl.IpuScene(d).set_option("cus", 5000)
+    sp = scenes["spheres"]
+    with _desc_restored(sp.desc) as d:
+        rng = np.random.default_rng(6)
+        ks, bs, relu = _nif_weights(rng, hidden=64, embed=12, layers=4)
+        d.set_image(96, 64); d.samples_per_pixel = 20; d.path_trace = 1
+        frames = []
+        for cus in (0, 3):
+            dev = irl.IpuScene(d).set_option("cus", cus)
+            dev.setNif(ks, bs, relu, 12, 3.43, np.array([-2.35, -2.26, -1.96], np.float32), True)
+            got = sp.init_ray_stream(); dev.run(got, irl.MODE_PATH_TRACE); dev.close()
+            frames.append(got)
+        assert_streams_identical(frames[1], frames[0], "NIF render on a grid for 3 compute units")
 
 
 def test_one_scene_on_two_streams_concurrently(scenes):
@@ -1169,7 +1252,7 @@ def test_nif_escaped_ray_with_nan_environment_coordinate(scenes):
     mean = np.array([-2.35, -2.26, -1.96], np.float32)
 
     def render(kernel):
-        dev = irl.IpuScene(d).set_option("kernel", kernel).set_option("nif_spl", case["nif_spl"])
+        dev = irl.IpuScene(d, variants=_needs_variants(kernel)).set_option("kernel", kernel).set_option("nif_spl", case["nif_spl"])
         dev.setNif(ks, bs, relu, 12, 3.43, mean, True)
         dev.setHdriRotation(case["hdri_rotation"])
         rays = s.init_ray_stream(); dev.run(rays, irl.MODE_PATH_TRACE); dev.close()
@@ -1260,6 +1343,51 @@ def test_double_fallback_variant_on_grazing_edge_rays_bit_exact():
 
 
 def test_fast_tier_within_its_stated_tolerance(scenes):
+    with _desc_restored(scenes["box"].desc):
+        _fast_tier_within_its_stated_tolerance(scenes)
+
+
+def test_fast_tier_axis_parallel_rays_and_refused_combinations(scenes):
+    """Rays that run parallel to an axis (a zero direction component: v_rcp_f32 gives an infinite 1/d) used to turn the FAST
+    box test's FMAs into inf - inf = NaN: every box read as hit and the ray walked the whole BVH. With anti-aliasing off,
+    the centre column / row of an even-sized image has primary rays with d.x == 0 / d.y == 0 exactly: the tier must name the
+    same primitive as the exact tier in every pixel, those included, at the same distance to 1e-6 - and finish in a time
+    that is not the whole-BVH walk's (the 64-column frame has 128 such rays; the check is on results, the walk length shows
+    in test time only). Combinations the tier has no build for are refused by mi_scene_set_option / mi_render instead of
+    silently rendering another tier."""
+    s = scenes["box"]
+    with _desc_restored(s.desc) as d:
+        d.set_image(64, 64); d.samples_per_pixel = 1; d.path_trace = 1; d.max_path_length = 1; d.anti_alias_scale = 0.0
+        exact = irl.IpuScene(d); fast = irl.IpuScene(d).set_option("fast", 1)
+        a = s.init_ray_stream(); exact.run(a, irl.MODE_PATH_TRACE)
+        b = s.init_ray_stream(); fast.run(b, irl.MODE_PATH_TRACE)
+        # pixelToRayDir (Render.hpp:74-85): x / w - 0.5 == 0 in column w / 2, y / h - 0.5 == 0 in row h / 2 (the record holds the
+        # direction AFTER the bounce, so the primary rays are named by their pixels)
+        par = (a["v"] == 32) | (a["u"] == 32)
+        assert par.sum() == 127, par.sum()
+        assert np.array_equal(a["h"]["primID"], b["h"]["primID"]) and np.array_equal(a["h"]["geomID"], b["h"]["geomID"])
+        hitm = a["h"]["primID"] != irl.INVALID_PRIM
+        assert (hitm & par).sum() > 20
+        ta, tb = a["h"]["r"]["tMax"][hitm], b["h"]["r"]["tMax"][hitm]
+        assert np.all(np.abs(ta - tb) <= 1e-6 * np.abs(ta))
+        # whole paths from those pixels stay sane too (mirror and wall bounces of axis-parallel rays)
+        d.max_path_length = 10; d.samples_per_pixel = 16
+        b = s.init_ray_stream(); fast.run(b, irl.MODE_PATH_TRACE)
+        assert np.isfinite(np.stack([b["rgb"][k] for k in "xyz"], 1)).all()
+        for key in ("full_stats", "double_fallback"):
+            with pytest.raises(irl.RaylibError, match="cannot be combined"):
+                fast.set_option(key, 1)
+        with pytest.raises(irl.RaylibError, match="cannot be combined"):
+            irl.IpuScene(d).set_option("double_fallback", 1).set_option("fast", 1)
+        rng = np.random.default_rng(3)
+        ks, bs, relu = _nif_weights(rng, hidden=32, layers=2)
+        fast.setNif(ks, bs, relu, 12, 3.43, np.array([-2.35, -2.26, -1.96], np.float32), True)
+        with pytest.raises(irl.RaylibError, match="tolerance tier"):
+            fast.run(s.init_ray_stream(), irl.MODE_PATH_TRACE)
+        exact.close(); fast.close()
+
+
+def _fast_tier_within_its_stated_tolerance(scenes):
     """Scene option "fast" = 1, the tolerance tier (never the default, never the headline): box test as FMAs on
     (plane, 1/d, -o/d) with a conservatively widened far side, triangle test contracted with v_rcp_f32 for 1/det. Same
     per-pixel RNG streams as the exact tier, so the two renders are compared pixel by pixel. Stated tolerance:

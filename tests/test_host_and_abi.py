@@ -253,7 +253,12 @@ def test_device_library_exports_every_declared_symbol():
             "mi_last_error", "mi_version"} <= set(names)
     for n in names:
         assert hasattr(lib, n), f"libmi_raylib.so does not export {n}"
-    assert b"gfx950" in lib.mi_version()
+    assert b"gfx950" in lib.mi_version() and b"+variants" not in lib.mi_version()
+    # the test build of the same sources (-DMI_RAYLIB_VARIANTS=1: the measured-and-rejected kernel families) keeps the same ABI
+    var = irl.device_lib(variants=True)
+    for n in names:
+        assert hasattr(var, n), f"libmi_raylib_variants.so does not export {n}"
+    assert b"+variants" in var.mi_version()
     hl = irl.host_lib()
     for n in _declared_functions(ROOT / "include" / "mi_scene_host.h"):
         assert hasattr(hl, n), f"libmi_scene_host.so does not export {n}"

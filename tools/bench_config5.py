@@ -13,7 +13,7 @@ N > 1   the C++ host path mi_group_* in ONE process: a scene replica per device 
 Prints ONE JSON line: ms per frame, ms per sample, the MLP's share of the GPU time (HIP events round every MLP launch:
 scene option "nif_timing"), paths/s, and for N > 1 `one_gpu_same_frame_ms` (the same frame on device 0 alone, same run),
 the RCCL message count and the number of distinct devices in the communicator."""
-import argparse, json, sys, time
+import argparse, json, os, sys, time
 from pathlib import Path
 import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
@@ -47,7 +47,6 @@ def one_gpu(d, scene, ks, bs, relu, steps, warmup, device=0):
     esc = float(((out["h"]["flags"] & irl.FLAG_ESCAPED) != 0).mean())
     res = {"ms_per_frame": el * 1e3, "mlp_ms_per_frame": tm["mlp_ms"] / steps, "mlp_launches_per_frame": tm["launches"] // steps,
            "paths": c["paths"] // steps, "casts": c["casts"] // steps, "escaped_fraction_last_sample": esc, "rgb_sum": float(out["rgb"]["x"].sum())}
-    import os
     if os.environ.get("MI_RAYLIB_FULL_STATS") == "1":
         p = dev.phase_stats(); cyc = p.pop("cycles")
         print("cycle shares:", {k: round(cyc[k] / cyc["total"], 3) for k in ("traverse", "shade", "gen")}, file=sys.stderr)
@@ -56,6 +55,8 @@ def one_gpu(d, scene, ks, bs, relu, steps, warmup, device=0):
 
 
 def main():
+    # (stdout carries the one JSON line: RCCL prints its version banner on stdout when a communicator is created)
+    sys.stdout.flush(); real_stdout = os.fdopen(os.dup(1), "w"); os.dup2(2, 1); sys.stdout = sys.stderr
     ap = argparse.ArgumentParser()
     ap.add_argument("spp", nargs="?", type=int, default=4000)
     ap.add_argument("size", nargs="?", type=int, default=1440)
@@ -78,7 +79,7 @@ def main():
                     "mlp_launches_per_frame": r["mlp_launches_per_frame"], "paths_per_s": r["paths"] / (r["ms_per_frame"] * 1e-3),
                     "casts_per_path": r["casts"] / max(r["paths"], 1), "escaped_fraction_last_sample": r["escaped_fraction_last_sample"],
                     "rgb_sum": r["rgb_sum"], "mlp_flops_per_ray": flops_per_ray})
-        print(json.dumps(out)); return
+        real_stdout.write(json.dumps(out) + "\n"); real_stdout.flush(); return
     devices = [int(x) for x in a.devices.split(",")] if a.devices else list(range(a.gpus))
     if len(devices) != a.gpus:
         raise SystemExit(f"bench_config5.py: --devices names {len(devices)} replicas, --gpus {a.gpus}")
@@ -115,7 +116,7 @@ def main():
                 "gather": {"rccl_messages": moved["rccl_messages"], "peer_copies": moved["peer_copies"]},
                 "one_gpu_same_frame_ms": anchor["ms_per_frame"], "one_gpu_mlp_share": anchor["mlp_ms_per_frame"] / anchor["ms_per_frame"],
                 "rgb_sum": float(got["rgb"]["x"].sum()), "one_gpu_rgb_sum_after_two_frames": anchor["rgb_sum"], "mlp_flops_per_ray": flops_per_ray})
-    print(json.dumps(out))
+    real_stdout.write(json.dumps(out) + "\n"); real_stdout.flush()
 
 
 if __name__ == "__main__":

@@ -21,11 +21,17 @@ def weights(rng, hidden=320, embed=12, layers=6):
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1440 * 1440
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("n", nargs="?", type=int, default=1440 * 1440)
+    ap.add_argument("--shape", default="w6", help="scene option nif_shape: w6 (default) | t6 | t4 (nif_mlp_kernel) | r8 | r8s (K3r, nif_regs_kernel.hpp)")
+    ap.add_argument("--reps", type=int, default=5)
+    a = ap.parse_args()
+    n = a.n
     rng = np.random.default_rng(0)
     ks, bs, relu, dims = weights(rng)
     s = irl.HostScene.builtin("spheres")
-    dev = irl.IpuScene(s.desc)
+    dev = irl.IpuScene(s.desc).set_option("nif_shape", a.shape)
     dev.setNif(ks, bs, relu, 12, 3.43, np.array([-2.35, -2.27, -1.96], np.float32), True)
     u = torch.rand(n, device="cuda"); v = torch.rand(n, device="cuda"); out = torch.empty(n, 3, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
@@ -33,7 +39,7 @@ def main():
         dev.nif_infer_device(u.data_ptr(), v.data_ptr(), out.data_ptr(), n, st)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 5
+    reps = a.reps
     e0.record()
     for _ in range(reps):
         dev.nif_infer_device(u.data_ptr(), v.data_ptr(), out.data_ptr(), n, st)
@@ -41,7 +47,7 @@ def main():
     ms = e0.elapsed_time(e1) / reps
     flops_per_ray = 2 * sum(k * c for k, c in dims)
     tf = n * flops_per_ray / (ms * 1e-3) / 1e12
-    print(json.dumps({"kernel": "nif_mlp_kernel", "rays": n, "ms": ms, "rays_per_s": n / (ms * 1e-3), "flops_per_ray": flops_per_ray,
+    print(json.dumps({"kernel": "nif_regs_kernel" if a.shape in ("r8", "r8s") else "nif_mlp_kernel", "shape": a.shape, "rays": n, "ms": ms, "rays_per_s": n / (ms * 1e-3), "flops_per_ray": flops_per_ray,
                       "tflops": tf, "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F16_PEAK_TFLOPS}}))
 
 

@@ -31,7 +31,10 @@ def main():
     stream = torch.cuda.current_stream()
     first = None
     for spec in a.specs:
-        dev = irl.IpuScene(d)
+        # (options of the kernel families outside the shipped library select the variants build of the same sources)
+        opts = dict(kv.split("=", 1) for kv in spec.split(":") if "=" in kv)
+        dev = irl.IpuScene(d, variants=(opts.get("kernel", "1") not in ("0", "1") or opts.get("spec", "0") != "0" or opts.get("waves", "5") != "5"
+                                        or any(k in opts for k in ("tune", "pool_waves", "pool_tune"))))
         for kv in spec.split(":"):
             k, v = kv.split("=", 1)
             dev.set_option(k, v)

@@ -21,7 +21,7 @@ def main():
     s.desc.set_image(edge, edge)
     s.desc.path_trace = 1
     s.desc.samples_per_pixel = spp
-    dev = irl.IpuScene(s.desc).set_option("full_stats", 1)
+    dev = irl.IpuScene(s.desc, variants=len(sys.argv) > 4).set_option("full_stats", 1)      # (extra options: the variants build)
     if len(sys.argv) > 4:
         for kv in sys.argv[4].split(":"):
             k, v = kv.split("=", 1)

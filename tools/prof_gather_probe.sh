@@ -5,6 +5,11 @@
 out=$1; cfg=$2
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 mkdir -p $R/$out
+# One un-profiled build first, then no compiling inside a profiled process: under `rocprofv3 --pmc` the preloaded tool has
+# initialised the GPU before python starts, and a compiler child (make -> sh -> gcc, hipcc -> clang) would be an exec after
+# GPU init, which the pool forbids. MI_NO_BUILD=1 turns every build_* helper into "fail fast on a stale binary".
+(cd $R && python3 -c 'import __graft_entry__ as ge; ge.build()') || { echo "build failed"; exit 1; }
+export MI_NO_BUILD=1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/stats -o st -- python3 $R/tools/gather_probe.py --only $cfg > $R/$out/stats.log 2>&1 || echo "stats failed"
 i=0

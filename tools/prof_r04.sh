@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-3 profile collection on one MI355X (one gpurun call). Counters-only passes, one --pmc group per run; kernel
-# times from separate --kernel-trace --stats runs. Everything lands under gpurun_out/prof_r03/; tools/collect_profiles.py
+# Round-4 profile collection on one MI355X (one gpurun call). Counters-only passes, one --pmc group per run; kernel
+# times from separate --kernel-trace --stats runs. Everything lands under gpurun_out/prof_r04/; tools/collect_profiles.py
 # turns it into the files under profiles/.
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/prof_r03
+OUT=$R/gpurun_out/prof_r04
 mkdir -p $OUT
 # One un-profiled build first, then no compiling inside a profiled process: under `rocprofv3 --pmc` the preloaded tool has
 # initialised the GPU before python starts, and a compiler child (make -> sh -> gcc, hipcc -> clang) would be an exec after
@@ -43,7 +43,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5/stats -o st -- p
 python3 $R/tools/gather_probe.py --out $OUT/gather_probe.json > $OUT/gather_probe.txt 2>&1 || echo "gather probe failed"
 for cfg in "tree35 0,1,35,5" "uni35 0,0,35,5" "tree64 0,1,64,5" "lds35 1,1,35,5"; do
   set -- $cfg
-  $R/tools/prof_gather_probe.sh gpurun_out/prof_r03/probe_$1 $2
+  $R/tools/prof_gather_probe.sh gpurun_out/prof_r04/probe_$1 $2
 done
 # the tolerance tier and the double-fallback variant next to the default kernel, same box
 python3 $R/tools/k_sweep.py --reps 3 kernel=1 fast=1 double_fallback=1 kernel=1 fast=1 > $OUT/variants.txt 2>&1 || echo "variants failed"
