@@ -3,8 +3,11 @@
 // PreTransformVertices | Triangulate | JoinIdenticalVertices | ... and then re-interprets materials.
 //
 // What is reproduced (rendering depends on nothing else):
-//   * geometry: <triangles> meshes, per-corner position/normal indices, node <matrix> transforms and
-//     the Z_UP -> Y_UP root rotation baked into the vertices (normals by the inverse transpose);
+//   * geometry: <triangles>, <polylist> and <polygons> primitives (polygons of more than three corners are cut into a fan
+//     from their first corner - what assimp's Triangulate step does for convex faces; holes, <ph>, are refused), every
+//     primitive group a mesh of its own with its own material, per-corner position/normal indices, node <matrix> transforms
+//     and the Z_UP -> Y_UP root rotation baked into the vertices (normals by the inverse transpose); a group of more than
+//     65 536 distinct vertices is split into several meshes (scene_types.hpp appendSplitMeshes: Triangle indices are 16 bit);
 //   * camera: first <instance_camera>; horizontal fov = xfov in radians; the view matrix assimp's
 //     aiCamera::GetCameraMatrix builds from the node-transformed position/lookAt/up; then the
 //     reference's "camera to origin + swap handedness" v = (-p.x, p.y, -p.z) (scene_utils.cpp:300-309);
@@ -266,6 +269,7 @@ SceneDescription importColladaScene(const std::string& path, bool loadNormals) {
       const M4 nrmM = inverseTranspose3(world);
       std::vector<const Xml*> prims = mesh->children("triangles");
       for (auto* pl : mesh->children("polylist")) prims.push_back(pl);
+      for (auto* pl : mesh->children("polygons")) prims.push_back(pl);
       for (auto* tri : prims) {
         uint32_t stride = 0, vOff = 0, nOff = ~0u;
         std::string nSource;
@@ -275,40 +279,55 @@ SceneDescription importColladaScene(const std::string& path, bool loadNormals) {
           if (in->get("semantic") == "VERTEX") vOff = off;
           if (in->get("semantic") == "NORMAL") { nOff = off; nSource = stripHash(in->get("source")); }
         }
-        const Xml* pe = tri->child("p");
-        if (!pe || !stride) continue;
-        if (tri->name == "polylist") {
-          if (const Xml* vc = tri->child("vcount")) for (uint32_t c : uints(vc->text)) if (c != 3) throw std::runtime_error("Only triangle meshes are supported.");
+        if (!stride) continue;
+        // the primitive group as a list of polygons: `idx` holds `stride` indices per corner, poly[i] corners per polygon
+        std::vector<uint32_t> idx, poly;
+        if (tri->name == "polygons") {
+          if (tri->child("ph")) throw std::runtime_error("dae: polygons with holes (<ph>) are not supported");
+          for (auto* pe : tri->children("p")) { const std::vector<uint32_t> one = uints(pe->text); poly.push_back((uint32_t)(one.size() / stride)); idx.insert(idx.end(), one.begin(), one.begin() + one.size() / stride * stride); }
+        } else {
+          const Xml* pe = tri->child("p");
+          if (!pe) continue;
+          idx = uints(pe->text);
+          if (tri->name == "polylist") { if (const Xml* vc = tri->child("vcount")) poly = uints(vc->text); }
+          if (poly.empty()) poly.assign(idx.size() / stride / 3, 3u);
         }
-        const std::vector<uint32_t> idx = uints(pe->text);
         const Source& ps = sources[posSource];
         const Source* ns = (nOff != ~0u && loadNormals) ? &sources[nSource] : nullptr;
-        TriMesh tm;
-        std::map<std::pair<uint32_t, uint32_t>, uint16_t> weld;   // (position index, normal index) -> vertex
-        const size_t corners = idx.size() / stride;
-        for (size_t c = 0; c < corners; ++c) {
+        std::vector<f3> verts, norms;
+        std::vector<uint32_t> tris;
+        std::map<std::pair<uint32_t, uint32_t>, uint32_t> weld;   // (position index, normal index) -> vertex
+        auto corner = [&](size_t c) -> uint32_t {
           const uint32_t pi = idx[c * stride + vOff], ni = ns ? idx[c * stride + nOff] : 0u;
           auto key = std::make_pair(pi, ni);
           auto it = weld.find(key);
           if (it == weld.end()) {
-            if (tm.vertices.size() >= 65536) throw std::runtime_error("dae: mesh has more than 65536 vertices (Triangle indices are 16 bit)");
             if ((size_t)pi * ps.stride + 2 >= ps.data.size()) throw std::runtime_error("dae: position index out of range");
             const f3 pos = mk(ps.data[pi * ps.stride], ps.data[pi * ps.stride + 1], ps.data[pi * ps.stride + 2]);
-            tm.vertices.push_back(xformPoint(world, pos));
+            verts.push_back(xformPoint(world, pos));
             if (ns) {
               if ((size_t)ni * ns->stride + 2 >= ns->data.size()) throw std::runtime_error("dae: normal index out of range");
               const f3 n = mk(ns->data[ni * ns->stride], ns->data[ni * ns->stride + 1], ns->data[ni * ns->stride + 2]);
-              tm.normals.push_back(normalized(xformDir(nrmM, n)));
+              norms.push_back(normalized(xformDir(nrmM, n)));
             }
-            it = weld.emplace(key, (uint16_t)(tm.vertices.size() - 1)).first;
+            it = weld.emplace(key, (uint32_t)(verts.size() - 1)).first;
           }
-          tm.indices.push_back(it->second);
+          return it->second;
+        };
+        size_t at = 0;
+        for (uint32_t cnt : poly) {
+          if (at + cnt > idx.size() / stride) throw std::runtime_error("dae: polygon list runs past its index data");
+          if (cnt >= 3) {
+            const uint32_t c0 = corner(at);
+            uint32_t prev = corner(at + 1);
+            for (uint32_t k = 2; k < cnt; ++k) { const uint32_t cur = corner(at + k); tris.push_back(c0); tris.push_back(prev); tris.push_back(cur); prev = cur; }
+          }
+          at += cnt;       // (points and lines - fewer than three corners - are dropped, as assimp's SortByPType does for the reference)
         }
-        tm.indices.resize(tm.indices.size() / 3 * 3);
-        if (tm.indices.empty()) continue;
+        if (tris.empty()) continue;
         const std::string matId = bind.count(tri->get("material")) ? bind[tri->get("material")] : tri->get("material");
-        scene.matIDs.push_back(materialIndex.count(matId) ? materialIndex[matId] : 0u);
-        scene.meshes.push_back(std::move(tm));
+        const size_t pieces = appendSplitMeshes(scene.meshes, verts, norms, tris);
+        for (size_t k = 0; k < pieces; ++k) scene.matIDs.push_back(materialIndex.count(matId) ? materialIndex[matId] : 0u);
       }
     }
     for (auto* ch : node->children("node")) walk(ch, world);

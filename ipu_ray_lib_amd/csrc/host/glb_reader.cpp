@@ -2,8 +2,9 @@
 //
 // Stands in for the assimp import the reference uses for assets/monkey_bust.glb
 // (src/scene_utils.cpp:102-150, flags PreTransformVertices | Triangulate | ...): every mesh
-// primitive of the default scene becomes one TriMesh with its node's TRS transform baked into
-// the positions (and the rotation into the normals). Vertex order is the file's order (assimp's
+// primitive of the default scene - a mesh may have several - becomes one TriMesh with its node's TRS transform baked into
+// the positions (and the rotation into the normals); indices of 8, 16 or 32 bits; a primitive of more than 65 536
+// vertices is split into several TriMeshes (scene_types.hpp appendSplitMeshes: Triangle indices are 16 bit). Vertex order is the file's order (assimp's
 // JoinIdenticalVertices re-indexing is not reproduced; only triangle vertex POSITIONS matter to
 // the renderer and those are unchanged by welding).
 #include <cstring>
@@ -108,17 +109,17 @@ void collect(const Glb& g, size_t nodeIndex, const Mat4& parent, bool loadNormal
     for (size_t p = 0; p < mesh.at("primitives").size(); ++p) {
       const auto& prim = mesh.at("primitives").at(p);
       if (prim.has("mode") && (int)prim.at("mode").number() != 4) continue;   // triangles only (SortByPType)
-      TriMesh tm;
+      std::vector<f3> verts, norms;
+      std::vector<uint32_t> tris;
       const AccessorView pos = accessor(g, (size_t)prim.at("attributes").at("POSITION").number());
       if (pos.componentType != 5126 || pos.numComp != 3) throw std::runtime_error("glb: POSITION must be float VEC3");
-      if (pos.count > 65536) throw std::runtime_error("glb: mesh has more than 65536 vertices (Triangle indices are 16 bit)");
-      tm.vertices.reserve(pos.count);
+      verts.reserve(pos.count);
       for (size_t i = 0; i < pos.count; ++i) {
         float v[3]; memcpy(v, pos.base + i * pos.stride, 12);
         const float* m = world.m;
-        tm.vertices.push_back(mk(m[0] * v[0] + m[1] * v[1] + m[2] * v[2] + m[3],
-                                 m[4] * v[0] + m[5] * v[1] + m[6] * v[2] + m[7],
-                                 m[8] * v[0] + m[9] * v[1] + m[10] * v[2] + m[11]));
+        verts.push_back(mk(m[0] * v[0] + m[1] * v[1] + m[2] * v[2] + m[3],
+                           m[4] * v[0] + m[5] * v[1] + m[6] * v[2] + m[7],
+                           m[8] * v[0] + m[9] * v[1] + m[10] * v[2] + m[11]));
       }
       if (loadNormals && prim.at("attributes").has("NORMAL")) {
         const AccessorView nrm = accessor(g, (size_t)prim.at("attributes").at("NORMAL").number());
@@ -127,14 +128,14 @@ void collect(const Glb& g, size_t nodeIndex, const Mat4& parent, bool loadNormal
         for (size_t i = 0; i < nrm.count; ++i) {
           float v[3]; memcpy(v, nrm.base + i * nrm.stride, 12);
           const float* m = world.m;   // rigid node transforms only: rotation part applies to normals
-          tm.normals.push_back(normalized(mk(m[0] * v[0] + m[1] * v[1] + m[2] * v[2],
-                                             m[4] * v[0] + m[5] * v[1] + m[6] * v[2],
-                                             m[8] * v[0] + m[9] * v[1] + m[10] * v[2])));
+          norms.push_back(normalized(mk(m[0] * v[0] + m[1] * v[1] + m[2] * v[2],
+                                        m[4] * v[0] + m[5] * v[1] + m[6] * v[2],
+                                        m[8] * v[0] + m[9] * v[1] + m[10] * v[2])));
         }
       }
       if (prim.has("indices")) {
         const AccessorView idx = accessor(g, (size_t)prim.at("indices").number());
-        tm.indices.reserve(idx.count);
+        tris.reserve(idx.count);
         for (size_t i = 0; i < idx.count; ++i) {
           uint32_t v = 0;
           const uint8_t* src = idx.base + i * idx.stride;
@@ -143,13 +144,22 @@ void collect(const Glb& g, size_t nodeIndex, const Mat4& parent, bool loadNormal
           else if (idx.componentType == 5121) { v = *src; }
           else throw std::runtime_error("glb: unsupported index type");
           if (v >= pos.count) throw std::runtime_error("glb: triangle index " + std::to_string(v) + " out of range (mesh has " + std::to_string(pos.count) + " vertices)");
-          tm.indices.push_back((uint16_t)v);
+          tris.push_back(v);
         }
       } else {
-        for (size_t i = 0; i < pos.count; ++i) tm.indices.push_back((uint16_t)i);
+        for (size_t i = 0; i < pos.count; ++i) tris.push_back((uint32_t)i);
       }
-      if (tm.indices.size() % 3) throw std::runtime_error("Only triangle meshes are supported.");
-      out.push_back(std::move(tm));
+      if (tris.size() % 3) throw std::runtime_error("Only triangle meshes are supported.");
+      if (pos.count <= 65536) {
+        // (the common case keeps the file's vertex order and its unreferenced vertices, as before)
+        TriMesh tm;
+        tm.vertices = std::move(verts); tm.normals = std::move(norms);
+        tm.indices.reserve(tris.size());
+        for (uint32_t v : tris) tm.indices.push_back((uint16_t)v);
+        out.push_back(std::move(tm));
+      } else {
+        appendSplitMeshes(out, verts, norms, tris);
+      }
     }
   }
   if (node.has("children"))

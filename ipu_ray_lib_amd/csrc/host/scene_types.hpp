@@ -29,6 +29,44 @@ struct TriMesh {
   void addQuad(f3 a, f3 b, f3 c, f3 d);   // two triangles (0,1,2) (2,3,0): scene_utils.cpp:31-46
 };
 
+// An indexed triangle list with 32-bit indices -> TriMeshes of at most 65 536 vertices each (`Triangle` indices are 16 bit,
+// include/Primitives.hpp:21-25; the reference hands assimp's 32-bit face indices to that constructor unchecked, so a larger
+// mesh comes out garbled there: splitting is this importer's answer). Greedy in triangle order: a piece is closed when
+// the next triangle's new vertices would not fit; a vertex shared across the cut is duplicated. Returns the pieces added.
+inline size_t appendSplitMeshes(std::vector<TriMesh>& out, const std::vector<f3>& vertices, const std::vector<f3>& normals,
+                                const std::vector<uint32_t>& indices, size_t maxVertices = 65536) {
+  size_t pieces = 0;
+  TriMesh cur;
+  std::vector<uint32_t> remap(vertices.size(), 0xFFFFFFFFu);
+  std::vector<uint32_t> used;      // vertices of the current piece (to reset their remap entries)
+  auto flush = [&] {
+    if (cur.indices.empty()) return;
+    out.push_back(std::move(cur)); ++pieces;
+    cur = TriMesh();
+    for (uint32_t v : used) remap[v] = 0xFFFFFFFFu;
+    used.clear();
+  };
+  for (size_t t = 0; t + 2 < indices.size(); t += 3) {
+    size_t fresh = 0;
+    for (int k = 0; k < 3; ++k) {
+      const uint32_t v = indices[t + k];
+      if (remap[v] == 0xFFFFFFFFu && (k < 1 || indices[t] != v) && (k < 2 || indices[t + 1] != v)) ++fresh;
+    }
+    if (cur.vertices.size() + fresh > maxVertices) flush();
+    for (int k = 0; k < 3; ++k) {
+      const uint32_t v = indices[t + k];
+      if (remap[v] == 0xFFFFFFFFu) {
+        remap[v] = (uint32_t)cur.vertices.size(); used.push_back(v);
+        cur.vertices.push_back(vertices[v]);
+        if (!normals.empty()) cur.normals.push_back(normals[v]);
+      }
+      cur.indices.push_back((uint16_t)remap[v]);
+    }
+  }
+  flush();
+  return pieces;
+}
+
 struct SceneDescription {
   std::vector<TriMesh> meshes;
   std::vector<mi_sphere> spheres;

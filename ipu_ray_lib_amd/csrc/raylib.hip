@@ -200,7 +200,8 @@ struct SceneOptions {
     static const char* const map[][2] = {{"MI_RAYLIB_FULL_STATS", "full_stats"}, {"MI_RAYLIB_KERNEL", "kernel"}, {"MI_RAYLIB_WAVES", "waves"}, {"MI_RAYLIB_SPEC", "spec"},
                                          {"MI_RAYLIB_SEG_BUDGET_KB", "seg_budget_kb"}, {"MI_RAYLIB_NIF_SPL", "nif_spl"}, {"MI_RAYLIB_PIN", "pin"},
                                          {"MI_RAYLIB_NIF_SHAPE", "nif_shape"}, {"MI_RAYLIB_TUNE", "tune"},
-                                         {"MI_RAYLIB_POOL_TUNE", "pool_tune"}, {"MI_RAYLIB_POOL_WAVES", "pool_waves"}, {"MI_RAYLIB_CUS", "cus"}};
+                                         {"MI_RAYLIB_POOL_TUNE", "pool_tune"}, {"MI_RAYLIB_POOL_WAVES", "pool_waves"}, {"MI_RAYLIB_CUS", "cus"},
+                                         {"MI_RAYLIB_NIF_OVERLAP", "nif_overlap"}};
     // (an unparsable environment value is ignored: the option keeps its default. The two options that select ARITHMETIC,
     // double_fallback and fast, are deliberately not in this list: a process that says "bit-exact" must not change tier
     // because of a variable somebody exported)
