@@ -36,6 +36,8 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" "SQ_INSTS_VA
   i=$((i+1))
   rocprofv3 --output-format csv --pmc $grp -d $OUT/nif/g$i -o pmc -- python3 $R/tools/bench_nif.py > $OUT/nif_g$i.log 2>&1 || echo "nif group $i failed"
 done
+# K3r (the register-resident MLP kernel, opt-in) next to K3: kernel stats + counters of the same workload
+$R/tools/prof_nif.sh gpurun_out/prof_r04/nif_r8 --shape r8 --reps 20 > $OUT/nif_r8.log 2>&1 || echo "nif r8 failed"
 # config 5 at its real size on one GPU: monkey + NIF, 1440^2 x 4000 spp, un-profiled for the wall time and with --stats for the kernel shares
 python3 $R/tools/bench_config5.py 4000 > $OUT/c5_full.json 2> $OUT/c5_full.err || echo "config 5 run failed"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5/stats -o st -- python3 $R/tools/bench_config5.py 512 > $OUT/c5_stats.log 2>&1 || echo "c5 stats failed"
@@ -46,7 +48,7 @@ for cfg in "tree35 0,1,35,5" "uni35 0,0,35,5" "tree64 0,1,64,5" "lds35 1,1,35,5"
   $R/tools/prof_gather_probe.sh gpurun_out/prof_r04/probe_$1 $2
 done
 # the tolerance tier and the double-fallback variant next to the default kernel, same box
-python3 $R/tools/k_sweep.py --reps 3 kernel=1 fast=1 double_fallback=1 kernel=1 fast=1 > $OUT/variants.txt 2>&1 || echo "variants failed"
+python3 $R/tools/k_sweep.py --reps 3 kernel=1 fast=1 double_fallback=1 cus=64 kernel=1 fast=1 > $OUT/variants.txt 2>&1 || echo "variants failed"
 # the un-profiled bench line of the same build
 python3 $R/bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err || echo "bench failed"
 echo done

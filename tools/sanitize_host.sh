@@ -12,4 +12,4 @@ g++ -std=c++17 -O1 -g -ffp-contract=off -fno-fast-math -fPIC -Wall -shared -fsan
 ln -sf $R/ipu_ray_lib_amd/libmi_nif_h5.so $R/build/san/libmi_nif_h5.so       # the HDF5 plugin is looked up beside the host library
 cd $R
 LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 \
-  MI_SCENE_HOST_LIB=$R/build/san/libmi_scene_host.so python -m pytest tests/test_host_and_abi.py tests/test_scene_blob.py tests/test_nif_assets.py tests/test_sharding_gloo.py -x -q -m "not gpu" "$@"
+  MI_SCENE_HOST_LIB=$R/build/san/libmi_scene_host.so python -m pytest tests/test_host_and_abi.py tests/test_scene_blob.py tests/test_nif_assets.py tests/test_importers.py tests/test_sharding_gloo.py -x -q -m "not gpu" "$@"
