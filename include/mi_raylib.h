@@ -221,8 +221,8 @@ int mi_scene_set_ray_batch(mi_scene* scene, size_t rays_per_batch);
  *   "tiles"         0 | 1           walk row-structured streams in 8x8 pixel tiles
  *   "seg_budget_kb" N >= 1          partial-sum buffer budget per launch
  *   "nif_spl"       0..128          NIF samples per launch (0 = default)
- *   "nif_shape"     w6 | t6 | t4 | r8 | r8s   workgroup shape of the NIF MLP kernel (w6 = default; r8 / r8s = the register-resident
- *                                   kernel of csrc/nif_regs_kernel.hpp for the network shapes it covers: measured slower, selectable)
+ *   "nif_shape"     w6 | t6 | t4    workgroup shape of the NIF MLP kernel (w6 = default); the variants build also takes r8 | r8s = the
+ *                                   register-resident kernel of csrc/nif_regs_kernel.hpp (measured slower; refused by the shipped library)
  *   "pin"           0 | 1           page-lock the caller's stream for the duration of mi_render
  *   "nif_overlap"   0 | 1           NIF renders trace sample batch b + 1 beside the MLP of batch b (two slot sets, a second stream; default 1)
  *   "nif_timing"    0 | 1           bracket every MLP launch of a NIF render with HIP events (mi_get_nif_timing)

@@ -164,7 +164,8 @@ def device_lib(variants: bool = False) -> C.CDLL:
             pass
         # (MI_RAYLIB_LIB: another build of the same library, for A/B timing of two builds on one box)
         if variants:
-            lib = _load(PKG_DIR / "libmi_raylib_variants.so")
+            # (MI_RAYLIB_VARIANTS_LIB: another build of the variants library, e.g. the timing-only builds of tools/k3r_knockouts.sh)
+            lib = _load(Path(os.environ["MI_RAYLIB_VARIANTS_LIB"]) if os.environ.get("MI_RAYLIB_VARIANTS_LIB") else PKG_DIR / "libmi_raylib_variants.so")
         else:
             lib = _load(Path(os.environ["MI_RAYLIB_LIB"]) if os.environ.get("MI_RAYLIB_LIB") else PKG_DIR / "libmi_raylib.so")
         lib.mi_last_error.restype = C.c_char_p

@@ -35,6 +35,9 @@
 #include "nif_regs_pack.hpp"
 #include "../../include/mi_raylib.h"
 
+#ifndef MI_RAYLIB_VARIANTS
+#define MI_RAYLIB_VARIANTS 0
+#endif
 #ifndef MI_NIF_STAMPS
 #define MI_NIF_STAMPS 0
 #endif
@@ -93,11 +96,15 @@ struct NifDevice {
   uint32_t* d_index = nullptr;     // compacted ray indices
   size_t indexCap = 0;
   bool ok = false;
-  NifRegsDevice regs;              // the same model packed for K3r (nif_regs_kernel.hpp); regs.ok only for the shapes that kernel covers
+#if MI_RAYLIB_VARIANTS
+  NifRegsDevice regs;              // the same model packed for K3r (nif_regs_kernel.hpp; variants build only); regs.ok only for the shapes that kernel covers
+#endif
 
   bool loaded() const { return ok; }
   void release() {
+#if MI_RAYLIB_VARIANTS
     regs.release();
+#endif
     if (d_weights) (void)hipFree(d_weights);
     if (d_count) (void)hipFree(d_count);
     if (d_index) (void)hipFree(d_index);
@@ -169,7 +176,9 @@ struct NifDevice {
     if (hipMalloc(&d_weights, packed.size() * sizeof(_Float16)) != hipSuccess) throw std::runtime_error("NIF: hipMalloc failed");
     (void)hipMemcpy(d_weights, packed.data(), packed.size() * sizeof(_Float16), hipMemcpyHostToDevice);
     if (hipMalloc(&d_count, sizeof(uint32_t)) != hipSuccess) throw std::runtime_error("NIF: hipMalloc failed");
+#if MI_RAYLIB_VARIANTS
     (void)regs.load(numLayers, kernels, biases, rows, cols, relu, embedDim, maxValue, mean, logTonemap);
+#endif
     p = P;
     ok = true;
   }
@@ -595,12 +604,14 @@ inline void nif_regs_launch(const NifRegsDevice& nr, const float* u, const float
 // bgrOut: result of row r at bgrOut[3r..] - or, with `scatter`, at bgrOut[3*idx[r]..] (the row's own slot)
 // shape (scene option "nif_shape"): 0 = w6 (default), 1 = t6, 2 = t4 (nif_mlp_kernel's workgroup shapes); 4 = r8, 5 = r8s = K3r, the
 // register-resident kernel of nif_regs_kernel.hpp (eight waves in lock-step / waves 4-7 staggered by a quarter chunk), for the
-// network shapes it covers - measured 6 % (r8) and 15 % (r8s) SLOWER than w6 (profiles/r04_k3r_attempt.txt), so never the default;
-// a network it does not cover runs w6
+// network shapes it covers - measured 6 % (r8) and 15 % (r8s) SLOWER than w6 (profiles/r04_k3r_attempt.txt), so never the default
+// and compiled into the variants build only; a network it does not cover runs w6
 inline void nif_launch_mlp(const NifDevice& nif, const float* u, const float* v, const uint32_t* idx, const uint32_t* countPtr,
                            uint32_t numRows, float* bgrOut, mi_trace_result* rays, hipStream_t stream, bool scatter = false, uint32_t shape = 0, uint32_t numCUs = 256) {
   if (numRows == 0) return;
+#if MI_RAYLIB_VARIANTS
   if (shape >= 4 && nif.regs.ok) { nif_regs_launch(nif.regs, u, v, idx, countPtr, numRows, bgrOut, rays, stream, scatter, numCUs, shape == 5 ? 0u : 1u); return; }
+#endif
   if (shape >= 3) shape = 0;
   uint32_t maxTiles = 1;
   for (uint32_t l = 0; l < nif.p.numLayers; ++l) maxTiles = std::max(maxTiles, nif.p.layers[l].nTiles / 4);

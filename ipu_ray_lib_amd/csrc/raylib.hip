@@ -18,16 +18,17 @@
 #include "trace_wavefront.hpp"
 // MI_RAYLIB_VARIANTS=1 (libmi_raylib_variants.so, the test build): the kernel families that were built, measured and not
 // made the default - LDS-staged nodes (kernel 2), the path pool (kernel 3), the speculative walk (spec), the 4-wave and
-// the runtime-weights instantiations (waves, tune) - stay selectable and parity-tested there. The
-// shipped library carries the default path, its instrumented build, the nested-loop kernel and the two arithmetic options.
+// the runtime-weights instantiations (waves, tune), the register-resident MLP kernel K3r (nif_shape r8 / r8s) - stay
+// selectable and parity-tested there. The
+// shipped library carries the default path, its instrumented build, the nested-loop kernel, the two arithmetic options and K3.
 #ifndef MI_RAYLIB_VARIANTS
 #define MI_RAYLIB_VARIANTS 0
 #endif
 #if MI_RAYLIB_VARIANTS
 #include "trace_pool.hpp"
+#include "nif_regs_kernel.hpp"      // K3r, the register-resident MLP kernel (round 4: correct, slower than K3; nif_shape r8 / r8s)
 #endif
 #include "nif_kernels.hpp"
-#include "nif_regs_kernel.hpp"
 #include "scene_blob.hpp"
 
 using namespace mi;
@@ -182,7 +183,13 @@ struct SceneOptions {
     }
     if (key == "nif_shape") {
       const std::string s(v);
-      if (s == "w6") nifShape = 0; else if (s == "t6") nifShape = 1; else if (s == "t4") nifShape = 2; else if (s == "r8") nifShape = 4; else if (s == "r8s") nifShape = 5; else return false;
+      if (s == "w6") nifShape = 0; else if (s == "t6") nifShape = 1; else if (s == "t4") nifShape = 2;
+#if MI_RAYLIB_VARIANTS
+      else if (s == "r8") nifShape = 4; else if (s == "r8s") nifShape = 5;
+#else
+      else if (s == "r8" || s == "r8s") { why = "K3r (nif_shape r8 / r8s) is not compiled into this library (the variants build, -DMI_RAYLIB_VARIANTS=1, has it)"; return false; }
+#endif
+      else return false;
       return true;
     }
 #if MI_RAYLIB_VARIANTS

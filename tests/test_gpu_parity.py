@@ -465,7 +465,7 @@ def test_nif_mlp_against_oracle(scenes, shape):
     mean = np.array([-2.3514461517333984, -2.2660605907440186, -1.9648972749710083], np.float32) - np.float32(1e-8)
     maxv = 3.4299468994140625
     s = scenes["spheres"]
-    dev = irl.IpuScene(s.desc).set_option("nif_shape", shape)
+    dev = irl.IpuScene(s.desc, variants=shape.startswith("r")).set_option("nif_shape", shape)      # (K3r lives in the variants build)
     dev.setNif(ks, bs, relu, 12, maxv, mean, True)
     n = 10000 + 37                                           # ragged: not a multiple of 64
     u = rng.random(n).astype(np.float32); v = rng.random(n).astype(np.float32)
@@ -501,7 +501,7 @@ def test_nif_mlp_shapes_against_oracle(scenes, hidden, layers, kernel):
     mean = np.array([-2.35, -2.27, -1.96], np.float32)
     maxv = 3.43
     s = scenes["spheres"]
-    dev = irl.IpuScene(s.desc).set_option("nif_shape", kernel)
+    dev = irl.IpuScene(s.desc, variants=kernel.startswith("r")).set_option("nif_shape", kernel)
     dev.setNif(ks, bs, relu, 12, maxv, mean, True)
     n = 3000 + 53
     u = rng.random(n).astype(np.float32); v = rng.random(n).astype(np.float32)
@@ -950,7 +950,7 @@ def test_scene_options_are_per_scene(scenes, monkeypatch):
     with pytest.raises(irl.RaylibError, match="unknown option"):
         plain.set_option("no_such_option", 1)
     # the shipped library carries the default path only: the measured-and-rejected kernel families are refused by name
-    for key, value in (("kernel", 2), ("kernel", 3), ("spec", 1), ("waves", 4), ("tune", "8,16,24"), ("pool_waves", 8)):
+    for key, value in (("kernel", 2), ("kernel", 3), ("spec", 1), ("waves", 4), ("tune", "8,16,24"), ("pool_waves", 8), ("nif_shape", "r8"), ("nif_shape", "r8s")):
         with pytest.raises(irl.RaylibError, match="not compiled into this library"):
             plain.set_option(key, value)
     plain.set_option("kernel", 1).set_option("spec", 0).set_option("waves", 5)      # the defaults are accepted

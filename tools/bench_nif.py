@@ -31,7 +31,7 @@ def main():
     rng = np.random.default_rng(0)
     ks, bs, relu, dims = weights(rng)
     s = irl.HostScene.builtin("spheres")
-    dev = irl.IpuScene(s.desc).set_option("nif_shape", a.shape)
+    dev = irl.IpuScene(s.desc, variants=a.shape.startswith("r")).set_option("nif_shape", a.shape)      # (K3r: the variants build)
     dev.setNif(ks, bs, relu, 12, 3.43, np.array([-2.35, -2.27, -1.96], np.float32), True)
     u = torch.rand(n, device="cuda"); v = torch.rand(n, device="cuda"); out = torch.empty(n, 3, device="cuda")
     st = torch.cuda.current_stream().cuda_stream

@@ -3,7 +3,7 @@
 #   tools/isa_k3r.sh [extra hipcc flags]
 R=$(cd $(dirname $0)/.. && pwd)
 mkdir -p $R/build/isa && cd $R/build/isa
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fPIC -shared -Wall -Wno-unused-function -I $R/include -DMI_NIF_REGS_ONLY10 "$@" -save-temps=obj -o libtest.so $R/ipu_ray_lib_amd/csrc/raylib.hip 2>&1 | grep -E "error" | head
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fPIC -shared -Wall -Wno-unused-function -I $R/include -DMI_RAYLIB_VARIANTS=1 -DMI_NIF_REGS_ONLY10 -mllvm -pragma-unroll-threshold=10000000 "$@" -save-temps=obj -o libtest.so $R/ipu_ray_lib_amd/csrc/raylib.hip 2>&1 | grep -E "error" | head
 S=raylib-hip-amdgcn-amd-amdhsa-gfx950.s
 k="ILj10ELj8ELj2ELj4ELb${STG:-1}E"
 a=$(grep -n "^_ZN2mi15nif_regs_kernel$k" $S | head -1 | cut -d: -f1); b=$(grep -n "\.amdhsa_kernel _ZN2mi15nif_regs_kernel$k" $S | head -1 | cut -d: -f1)
