@@ -1,4 +1,7 @@
 // nif_regs_kernel.hpp — K3r: the NIF MLP with the ACTIVATIONS IN REGISTERS and the WEIGHTS STREAMED THROUGH LDS.
+// Round 4's attempt at the MLP kernel; compiled into the VARIANTS build only (libmi_raylib_variants.so, scene option nif_shape
+// = r8 | r8s): it reproduces the oracle in every test and runs 6 % slower than nif_mlp_kernel on fast boxes (1.6 % faster on a
+// clock-limited one) - the builds, PMC rows and knock-outs are in profiles/r04_k3r_attempt.txt, the reading in DESIGN.md §13.
 //
 // Same mathematics as nif_mlp_kernel (nif_kernels.hpp; reference: src/neural_networks/NifModel.cpp:186-246 encode /
 // decode, :300-327 dense stack; numerics of the reference's fp16 model: binary16 features, weights and inter-layer
@@ -15,14 +18,17 @@
 //     accumulators to the next layer's operand registers through a convert, a ReLU and nothing else: no activation
 //     ever touches LDS, no barrier separates the layers.
 //   * what goes through LDS instead is the weight stream, ONCE per workgroup pass of 256 rays (8 waves x 32): 1.09 MB
-//     per 256 rays = 8.8 GB per launch, 0.38 x the L2 traffic. The stream is cut into chunks of two output-tile pairs
-//     (40 or 48 fragments of 1 KiB), brought in by LDS-DMA (global_load_lds_dwordx4: no staging registers) into a ring
-//     of three slots, two chunks ahead of the MFMAs; one workgroup barrier per chunk (80 - 96 MFMAs per wave).
+//     per 256 rays = 8.8 GB per launch, 0.38 x the L2 traffic. A layer's fragments are one straight run in consumption
+//     order, cut into chunks of 4 HT fragments of 1 KiB (40 for width 320; a hidden layer is a whole number of chunks),
+//     brought in by LDS-DMA (global_load_lds_dwordx4: no staging registers) into a ring of three slots, two chunks ahead
+//     of the MFMAs, the pieces issued one at a time between MFMAs; one workgroup barrier per chunk (80 MFMAs per wave).
 //     Every A fragment a wave reads from LDS (ds_read_b128, conflict-free: 64 lanes x 16 contiguous bytes) feeds two
 //     MFMAs; eight waves at full matrix rate read 128 B/clk/CU, half of the LDS's 256 (MI355X_MICROARCH.md, LDS table).
 //
-// A workgroup is 8 waves = 2 per SIMD, 1 workgroup per CU (the ring takes 120 - 144 KiB of LDS). Registers per lane:
-// input 80 + output 80 (10 k-steps x 2 ray tiles x 4) + features 16 + accumulators 16 + fragments in flight.
+// A workgroup is 8 waves = 2 per SIMD, 1 workgroup per CU (ring 120 KiB + a 32-KiB image of the pass's Fourier features as B
+// fragments, one 4-KiB part per wave, + the biases). Registers per lane: input 80 + output 80 (10 k-steps x 2 ray tiles x 4)
+// + accumulators 16 + a four-deep fragment ring 16 + bias 8 - hipcc wants ~30 more than the 256 there are and spills a few
+// finished output values per layer; what matters is that NO scratch access sits between LDS-DMA issues (see below).
 //
 // Shapes: hidden width H a multiple of 32 up to 320 (instantiated for H = 64, 128, 256, 320), every hidden layer H wide,
 // inputs of F = 4 * embedding <= 64 Fourier features, a layer's input either the previous layer's output or that
