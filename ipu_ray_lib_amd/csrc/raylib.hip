@@ -105,6 +105,7 @@ struct SceneOptions {
   uint32_t nifSamplesPerLaunch = 0;               // MI_RAYLIB_NIF_SPL / "nif_spl": 0 = default (128, memory permitting)
   bool pin = true;                 // MI_RAYLIB_PIN / "pin": page-lock the caller's stream for the duration of mi_render
   uint32_t nifShape = 0;           // MI_RAYLIB_NIF_SHAPE / "nif_shape": 0 = w6 (default), 1 = t6, 2 = t4; 4 = r8, 5 = r8s (K3r, nif_regs_kernel.hpp: measured slower, selectable)
+  bool coords = true;              // "coords": (pixel, segment) atoms read the pixel coordinates from a compact copy of the stream's (u, v)
   bool nifOverlap = true;          // "nif_overlap": NIF renders trace sample batch b + 1 beside the MLP of batch b (two slot sets, second stream)
   bool nifTiming = false;          // "nif_timing": HIP events round every MLP launch of a NIF render (mi_get_nif_timing)
   // the two options that select ARITHMETIC (every other option leaves every result bit alone):
@@ -166,6 +167,7 @@ struct SceneOptions {
     if (key == "pin") return flag01(v, pin);
     if (key == "nif_timing") return flag01(v, nifTiming);
     if (key == "nif_overlap") return flag01(v, nifOverlap);
+    if (key == "coords") return flag01(v, coords);
     if (key == "double_fallback") {
       bool b = doubleFallback;
       if (!flag01(v, b)) return false;
@@ -208,7 +210,7 @@ struct SceneOptions {
                                          {"MI_RAYLIB_SEG_BUDGET_KB", "seg_budget_kb"}, {"MI_RAYLIB_NIF_SPL", "nif_spl"}, {"MI_RAYLIB_PIN", "pin"},
                                          {"MI_RAYLIB_NIF_SHAPE", "nif_shape"}, {"MI_RAYLIB_TUNE", "tune"},
                                          {"MI_RAYLIB_POOL_TUNE", "pool_tune"}, {"MI_RAYLIB_POOL_WAVES", "pool_waves"}, {"MI_RAYLIB_CUS", "cus"},
-                                         {"MI_RAYLIB_NIF_OVERLAP", "nif_overlap"}};
+                                         {"MI_RAYLIB_NIF_OVERLAP", "nif_overlap"}, {"MI_RAYLIB_COORDS", "coords"}};
     // (an unparsable environment value is ignored: the option keeps its default. The two options that select ARITHMETIC,
     // double_fallback and fast, are deliberately not in this list: a process that says "bit-exact" must not change tier
     // because of a variable somebody exported)
@@ -226,6 +228,7 @@ struct LaunchSlot {
   hipStream_t stream = nullptr;
   uint32_t* d_workCounter = nullptr;
   float* d_segPart = nullptr; size_t segPartFloats = 0;     // [segments][n][3]
+  float2* d_coords = nullptr; size_t coordsCap = 0;         // the stream's pixel coordinates, compact (WaveExtras::coords)
   uint32_t* d_poolScratch = nullptr; size_t poolScratchWords = 0;   // kernel 3 (variants build): [PG_WORDS][slots of the grid]
 };
 
@@ -284,7 +287,7 @@ struct mi_scene {
     for (NifSlots& q : nifSlots) { if (q.count) (void)hipFree(q.count); if (q.traced) (void)hipEventDestroy(q.traced); if (q.done) (void)hipEventDestroy(q.done); }
     if (nifAux) (void)hipStreamDestroy(nifAux);
     if (d_segTotal) (void)hipFree(d_segTotal);
-    for (LaunchSlot& l : slots) { if (l.d_workCounter) (void)hipFree(l.d_workCounter); if (l.d_segPart) (void)hipFree(l.d_segPart); if (l.d_poolScratch) (void)hipFree(l.d_poolScratch); }
+    for (LaunchSlot& l : slots) { if (l.d_workCounter) (void)hipFree(l.d_workCounter); if (l.d_segPart) (void)hipFree(l.d_segPart); if (l.d_coords) (void)hipFree(l.d_coords); if (l.d_poolScratch) (void)hipFree(l.d_poolScratch); }
     for (int i = 0; i < 2; ++i) { if (d_batch[i]) (void)hipFree(d_batch[i]); if (pipeStream[i]) (void)hipStreamDestroy(pipeStream[i]); }
     if (nifDone) (void)hipEventDestroy(nifDone);
     for (auto& e : nifTimes) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -548,9 +551,22 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
     }
   }
   const uint32_t launches = segmented ? (segments + perLaunch - 1) / perLaunch : 1u;
+  // (pixel, segment) atoms fetch a pixel's coordinates once per segment: from a compact copy, gathered here
+  const float2* coords = nullptr;
+  if ((segmented || !plain) && S.opt.coords) {
+    if (slot.coordsCap < cnt) {
+      if (slot.d_coords) { HIP_CHECK(hipStreamSynchronize(stream)); (void)hipFree(slot.d_coords); }
+      slot.d_coords = nullptr; slot.coordsCap = 0;
+      HIP_CHECK(hipMalloc(&slot.d_coords, (size_t)cnt * sizeof(float2)));
+      slot.coordsCap = cnt;
+    }
+    hipLaunchKernelGGL(pixel_coords_kernel, dim3((cnt + 255) / 256), dim3(256), 0, stream, d_rays, cnt, slot.d_coords);
+    coords = slot.d_coords;
+  }
   for (uint32_t l = 0; l < launches; ++l) {
     const uint32_t segBase = l * perLaunch;
     WaveExtras exs = ex;
+    exs.coords = coords;
     if (segmented) { exs.segPart = slot.d_segPart; exs.segments = std::min(perLaunch, segments - segBase); exs.segBase = segBase; }
     HIP_CHECK(hipMemsetAsync(workCounter, 0, sizeof(uint32_t), stream));
     const uint64_t items = (uint64_t)cnt * ((segmented || !plain) ? exs.segments : 1u);     // work atoms of this launch

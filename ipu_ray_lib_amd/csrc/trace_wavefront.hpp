@@ -67,6 +67,10 @@ struct WaveExtras {
   float* segPart = nullptr;      // [segments][n][3]
   uint32_t segments = 1;
   uint32_t segBase = 0;
+  // The stream's pixel coordinates (TraceResult::u, ::v) as a compact array [n] of float pairs, gathered once per launch
+  // (pixel_coords_kernel): an atom's FETCH then reads 8 contiguous bytes instead of pulling a 64-byte sector of the 84-byte
+  // record out of HBM - sixteen times per pixel at 1000 spp, which was most of the frame's HBM traffic.
+  const float2* coords = nullptr;
 };
 
 // SPEC: a lane whose walk reaches a primitive whose box it hits does not wait for the LEAF turn: it notes the primitive
@@ -211,7 +215,8 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
             entry = ((t / perRow) * 8u + (within >> 3)) * tileStreamW + (t % perRow) * 8u + (within & 7u);
           }
           const mi_trace_result* res = rays + entry;
-          prow = res->u; pcol = res->v;
+          if (ex.coords) { const float2 pc = ex.coords[entry]; prow = pc.x; pcol = pc.y; }
+          else { prow = res->u; pcol = res->v; }
           coldU(0) = entry; coldF(1) = prow; coldF(2) = pcol;
           if (seg == 0) { coldF(3) = res->rgb.x; coldF(4) = res->rgb.y; coldF(5) = res->rgb.z; }
           else { coldF(3) = 0.f; coldF(4) = 0.f; coldF(5) = 0.f; }           // a later segment's own partial sum
@@ -621,6 +626,12 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
     atomicAdd(&sc.counters[12], tTrav); atomicAdd(&sc.counters[13], tShade); atomicAdd(&sc.counters[14], tGen);
     atomicAdd(&sc.counters[15], __builtin_amdgcn_s_memtime() - tLoop0);
   }
+}
+
+// WaveExtras::coords of a stream
+__global__ void __launch_bounds__(256) pixel_coords_kernel(const mi_trace_result* rays, uint32_t n, float2* __restrict__ coords) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) coords[i] = make_float2(rays[i].u, rays[i].v);
 }
 
 // rgb of a segmented pixel: ((segment 0, which started from the incoming rgb) + segment 1) + ... in segment order.

@@ -117,7 +117,8 @@ for tag, kern in (("c2", "path_trace_wavefront_kernel<false"), ("c3", "path_trac
             "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c["WRITE_SIZE"],
             "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE counts 128-B requests at 64 B -> doubled; WRITE_SIZE exact. The ray-record reads are 20 B out of every 84-B record, an access width the guide calls uncalibrated, so the doubled figure is an upper bound.",
             "hbm_bytes_per_launch": int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024),
-            "algorithmic_hbm_bytes_per_launch": int(2073600 * (84 + 84 + 16 * (84 + 12) + 16 * 12)),
+            "algorithmic_hbm_bytes_per_launch": int(2073600 * (84 + 84)),        # a TraceResult in and out once per pixel per frame
+            "helper_kernels_note": "per frame, beside this kernel: pixel_coords_kernel (the compact (u, v) copy the (pixel, segment) atoms fetch from) 0.19 GB, segment_combine_kernel 0.48 GB (gpurun_out/r4q PMC passes)",
             "valu": {"insts_per_cast": c["SQ_INSTS_VALU"] / casts, "salu_insts_per_cast": c["SQ_INSTS_SALU"] / casts,
                      "busy": c["SQ_INSTS_VALU"] * 2 / (SIMDS * cycles), "lanes_active": c["SQ_THREAD_CYCLES_VALU"] / (64 * c["SQ_ACTIVE_INST_VALU"]),
                      "useful_lane_ops_frac": c["SQ_INSTS_VALU"] * 2 / (SIMDS * cycles) * c["SQ_THREAD_CYCLES_VALU"] / (64 * c["SQ_ACTIVE_INST_VALU"]),

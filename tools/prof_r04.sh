@@ -26,6 +26,10 @@ run_set() {   # tag, then the program and its arguments
 
 # config 2 (headline): bench.py itself
 run_set c2 python3 $R/bench.py $BENCH
+if [ "$ONLY" = c2 ]; then      # (re-collection of the headline set alone, e.g. after a change that only touches K1w's launch)
+  python3 $R/bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err || echo "bench failed"
+  echo done; exit 0
+fi
 # config 3 scene (test_scene.dae with vertex normals) and the 16-spp box frame: one timed launch each
 run_set c3 python3 $R/tools/k_sweep.py --file $R/assets/test_scene.dae --spp 4000 --reps 1 kernel=1
 run_set spp16 python3 $R/tools/k_sweep.py --spp 16 --reps 8 kernel=1
