@@ -212,7 +212,8 @@ int mi_scene_set_ray_batch(mi_scene* scene, size_t rays_per_batch);
  * by the MI_RAYLIB_* environment variables as they stand when the scene is created, then by this call. Keys and the
  * values each accepts (anything else: MI_ERR_INVALID_ARG, the option keeps its value):
  *   "kernel"        0 | 1 | 2 | 3   nested-loop / phase-scheduled (default) / phase-scheduled + LDS-staged nodes / path pool
- *   "waves"         4 | 5           waves per SIMD the default kernel is built for (5: the 96-VGPR build)
+ *   "waves"         4 | 5 | 6       waves per SIMD the default kernel is built for (5: the 96-VGPR build, the default; 4 and 6 - the 80-VGPR
+ *                                   build, measured no faster - only in the variants build)
  *   "spec"          0 | 1           kernel 1: lanes walk on past ONE pending primitive test
  *   "full_stats"    0 | 1           instrumented kernels: node / leaf-test counters, phase occupancy
  *   "tune"          "leafAt,shadeAt,genAt[,burst,keep8,dbl,maxExtra(<=7),leafThenNode,prio,leafP]"   scheduling weights of kernel 1
@@ -226,6 +227,8 @@ int mi_scene_set_ray_batch(mi_scene* scene, size_t rays_per_batch);
  *   "pin"           0 | 1           page-lock the caller's stream for the duration of mi_render
  *   "nif_overlap"   0 | 1           NIF renders trace sample batch b + 1 beside the MLP of batch b (two slot sets, a second stream; default 1)
  *   "nif_timing"    0 | 1           bracket every MLP launch of a NIF render with HIP events (mi_get_nif_timing)
+ *   "coords"        0 | 1           (pixel, segment) work units read the pixel's (u, v) from a compact copy of the stream gathered once
+ *                                   per launch, not from the 84-byte record (default 1: a third of the HBM traffic)
  *   "cus"           0..4096         compute units the launch grids are sized for (0 = what the device reports; grids are
  *                                   units x workgroups resident per unit, asked of the runtime per kernel)
  * None of them changes a result bit. Two further keys select ARITHMETIC:

@@ -98,7 +98,7 @@ struct SceneOptions {
   uint32_t cus = 0;                // "cus": compute units the launch grids are sized for (0 = what the device reports)
   std::string why;                 // why the last set() returned false
   int poolWaves = 4;               // MI_RAYLIB_POOL_WAVES / "pool_waves": waves per workgroup of the path-pool kernel, 4 | 8 | 16 (400 | 800 | 1600 slots)
-  int wavesPerSimd = 5;            // MI_RAYLIB_WAVES / "waves": 4 = the 108-VGPR build of the default kernel
+  int wavesPerSimd = 5;            // MI_RAYLIB_WAVES / "waves": 4 = the 108-VGPR build of the default kernel, 6 = the 80-VGPR build (variants build)
   bool specLeaf = false;           // MI_RAYLIB_SPEC / "spec": lanes walk on past ONE pending primitive test (trace_wavefront.hpp, SPEC)
   bool tiles = true;               // MI_RAYLIB_NO_TILES / "tiles": walk row-structured streams in 8x8 pixel tiles
   size_t segBudgetKb = (size_t)8 * 1024 * 1024;   // MI_RAYLIB_SEG_BUDGET_KB / "seg_budget_kb": partial-sum buffer budget per launch
@@ -148,7 +148,7 @@ struct SceneOptions {
       poolTune = {a, b, c ? c : 1, d ? d : 1, e, f, db ? db : 65, mx, ln, pr};
       return true;
     }
-    if (key == "waves") { if (!number(v, 4, 5, q)) return false; wavesPerSimd = (int)q; return true; }
+    if (key == "waves") { if (!number(v, 4, 6, q)) return false; wavesPerSimd = (int)q; return true; }
     if (key == "spec") return flag01(v, specLeaf);
 #else
     if (key == "kernel") {
@@ -195,11 +195,11 @@ struct SceneOptions {
       return true;
     }
 #if MI_RAYLIB_VARIANTS
-    if (key == "tune") {      // leafAt,shadeAt,genAt[,burst,keep8,dbl,maxExtra,leafThenNode,prio,leafP]
-      unsigned a, b, c, dd = 48, k8 = 3, db = 4, mx = 6, ln = 1, pr = 1, lp = 40;
-      if (sscanf(v, "%u,%u,%u,%u,%u,%u,%u,%u,%u,%u", &a, &b, &c, &dd, &k8, &db, &mx, &ln, &pr, &lp) < 3) return false;
-      if (mx > 7) return false;          // the spelled-out run of box tests has eight
-      tune = {a, b, c, dd, k8, db ? db : 65, mx, ln, pr, lp ? lp : 1};
+    if (key == "tune") {      // leafAt,shadeAt,genAt[,burst,keep8,dbl,maxExtra,leafThenNode,prio,leafP,probe]
+      unsigned a, b, c, dd = 48, k8 = 3, db = 4, mx = 6, ln = 1, pr = 1, lp = 40, pb = 0;
+      if (sscanf(v, "%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u", &a, &b, &c, &dd, &k8, &db, &mx, &ln, &pr, &lp, &pb) < 3) return false;
+      if (mx > 7 || pb > 3) return false;          // the spelled-out run of box tests has eight
+      tune = {a, b, c, dd, k8, db ? db : 65, mx, ln, pr, lp ? lp : 1, pb};
       return true;
     }
 #endif
@@ -577,6 +577,10 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
       return (uint32_t)std::min<uint64_t>((items + threads - 1) / threads, (uint64_t)S.cus() * S.residentBlocks(reinterpret_cast<const void*>(kern), (int)threads, ldsBytes));
     };
     auto go = [&](auto kern) {
+#if MI_RAYLIB_VARIANTS
+      static const bool say = getenv("MI_RAYLIB_SAY_GRID") != nullptr;      // (test build: what the runtime said stays resident)
+      if (say) fprintf(stderr, "mi_raylib: grid %u workgroups = %u units x %u resident\n", grid(kern, 256, 0), S.cus(), S.residentBlocks(reinterpret_cast<const void*>(kern), 256, 0));
+#endif
       hipLaunchKernelGGL(kern, dim3(grid(kern, 256, 0)), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
     };
     if (S.opt.doubleFallback) {
@@ -628,6 +632,8 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
       else go(path_trace_wavefront_kernel<STATS, false, 256, 4, true>);
     } else if (!STATS && S.opt.wavesPerSimd == 5 && !(S.opt.tune == kDefaultTune)) {
       go(path_trace_wavefront_kernel<false, false, 256, 5>);            // runtime weights (tune sweeps): 42 scalar spills, 4 % slower
+    } else if (!STATS && S.opt.wavesPerSimd == 6 && plain) {
+      go(path_trace_wavefront_kernel<false, false, 256, 6, false, 0, true>);   // the 80-VGPR build: six waves per SIMD
 #endif
     } else if (!STATS && S.opt.wavesPerSimd == 5) {
       // the default path. 96-VGPR build, 5 waves per SIMD (+4.6 % on the box scene; 6 waves = 80 VGPRs: -19 %, its spills land
@@ -653,7 +659,8 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
     else hipLaunchKernelGGL(shadow_trace_kernel<false>, grid, block, 0, stream, S.ds, d_rays, cnt, .05f, light);
   } else if (mode == MI_MODE_PATH_TRACE) {
     // (the ALLOW_DOUBLE_FALLBACK=1 variant is compiled into the phase-scheduled kernel and the shadow kernel: it always takes them)
-    const bool nested = S.opt.kernelChoice == 0 && !S.opt.doubleFallback;
+    // (the phase-scheduled kernel keeps a path's bounce count in 30 bits)
+    const bool nested = (S.opt.kernelChoice == 0 || S.ds.maxPathLength >= (1u << 30)) && !S.opt.doubleFallback;
     if (!S.nif.loaded() && !nested && S.ds.samplesPerPixel >= 1 && S.ds.maxPathLength >= 1) {
       // sample loop inside the kernel (src/IpuScene.cpp:441), phase-scheduled persistent form
       if (S.opt.fullStats) launchWavefront<true>(S, d_rays, cnt, stream);

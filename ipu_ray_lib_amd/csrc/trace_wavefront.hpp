@@ -37,8 +37,10 @@ enum : uint32_t { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_GEN = 3, PH_FETCH =
 //   prio     1: waves run their traversal turns at s_setprio 1 (short dependent steps win VALU arbitration over
 //            another wave's long SHADE/GEN blocks: +1 %), 0: no priorities
 //   leafP    (SPEC build) a LEAF turn also runs once this many lanes hold a pending primitive test
-struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, dbl = 4, maxExtra = 6, leafThenNode = 1, prio = 1, leafP = 40;
-  bool operator==(const WaveTune& o) const { return leafAt == o.leafAt && shadeAt == o.shadeAt && genAt == o.genAt && burst == o.burst && keep8 == o.keep8 && dbl == o.dbl && maxExtra == o.maxExtra && leafThenNode == o.leafThenNode && prio == o.prio && leafP == o.leafP; } };
+//   probe    (runtime-weights build only; results unchanged) knock-ins that price a resource: bit 0 = every box test issues one
+//            more 16-byte load of its node (vector-memory path), bit 1 = eight more independent VALU instructions per box test
+struct WaveTune { uint32_t leafAt, shadeAt, genAt, burst, keep8, dbl = 4, maxExtra = 6, leafThenNode = 1, prio = 1, leafP = 40, probe = 0;
+  bool operator==(const WaveTune& o) const { return leafAt == o.leafAt && shadeAt == o.shadeAt && genAt == o.genAt && burst == o.burst && keep8 == o.keep8 && dbl == o.dbl && maxExtra == o.maxExtra && leafThenNode == o.leafThenNode && prio == o.prio && leafP == o.leafP && probe == o.probe; } };
 
 // Per-launch extras for renders with the NIF environment. The reference traces ONE sample, evaluates the
 // environment for the rays that escaped, adds it, and repeats (src/IpuScene.cpp:571-583). One sample per launch
@@ -99,7 +101,12 @@ __device__ __forceinline__ void fast_box_setup(f3 o, f3& inv, f3& oi, float& sla
   slabPad = 4.8e-7f * fmaxf(fmaxf(px ? 0.f : fabsf(oi.x), py ? 0.f : fabsf(oi.y)), pz ? 0.f : fabsf(oi.z));
 }
 
-constexpr WaveTune kDefaultTune = {8, 16, 24, 48, 3, 4, 6, 1, 1, 40};      // re-swept on the round-3 kernel on two scenes (profiles/r03_kernel_ab.txt): a cheaper box test favours one more of them per vote
+// How many lanes below this one are set in `mask` (v_mbcnt: no per-lane bit mask held in registers across the kernel).
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+constexpr WaveTune kDefaultTune = {8, 16, 24, 48, 3, 4, 6, 1, 1, 40, 0};      // re-swept on the round-3 kernel on two scenes (profiles/r03_kernel_ab.txt): a cheaper box test favours one more of them per vote
 // DF: the reference's ALLOW_DOUBLE_FALLBACK=1 build of the triangle test (trace_kernels.hpp). FAST: the tolerance tier
 // (scene option "fast"): the box test as three pairs of FMAs on (plane, 1/d, -o/d), the triangle test contracted, no
 // literal NaN-exact fallback - results within a stated tolerance of the exact tier's, not bit-identical.
@@ -169,16 +176,16 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
   auto pathLoad = [&]() {
     rng.s0 = (uint64_t)coldU(8) | ((uint64_t)coldU(9) << 32); rng.s1 = (uint64_t)coldU(10) | ((uint64_t)coldU(11) << 32);
     color = mk(coldF(12), coldF(13), coldF(14)); tp = mk(coldF(15), coldF(16), coldF(17)); nrm = mk(coldF(18), coldF(19), coldF(20));
-    bounce = coldU(21); sample = coldU(22);
+    { const uint32_t w = coldU(21); bounce = w >> 2; oFlags = w & 3u; } sample = coldU(22);     // (MI_FLAG_ERROR | MI_FLAG_ESCAPED ride in the bounce word: the host sends path lengths of 2^30 and more to K1)
   };
   auto pathStore = [&]() {
     coldU(8) = (uint32_t)rng.s0; coldU(9) = (uint32_t)(rng.s0 >> 32); coldU(10) = (uint32_t)rng.s1; coldU(11) = (uint32_t)(rng.s1 >> 32);
     coldF(12) = color.x; coldF(13) = color.y; coldF(14) = color.z; coldF(15) = tp.x; coldF(16) = tp.y; coldF(17) = tp.z;
     coldF(18) = nrm.x; coldF(19) = nrm.y; coldF(20) = nrm.z;
-    coldU(21) = bounce; coldU(22) = sample;
+    coldU(21) = (bounce << 2) | oFlags; coldU(22) = sample;
   };
   CastStats cs = {0, 0};
-  uint32_t casts = 0, paths = 0;
+  uint32_t casts = 0, paths = 0;       // wave-uniform: counted per turn from the turn's ballots, so they live in scalar registers
   // STATS only: per-wave phase executions and the lanes that were active in them (wave-uniform values)
   uint32_t itN = 0, itL = 0, itS = 0, itG = 0, lnN = 0, lnL = 0, lnS = 0, lnG = 0;
   unsigned long long tTrav = 0, tShade = 0, tGen = 0, tLoop0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;   // STATS: shader cycles per phase
@@ -197,7 +204,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
         chunkNext = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(base, firstF));
         chunkEnd = chunkNext + fetchChunk;
       }
-      const uint32_t avail = chunkEnd - chunkNext, rankF = (uint32_t)__popcll(mF & ((1ull << lane) - 1ull));
+      const uint32_t avail = chunkEnd - chunkNext, rankF = lane_rank(mF);
       const uint32_t chunkBase = chunkNext;
       chunkNext += min((uint32_t)__popcll(mF), avail);
       if (ph == PH_FETCH && rankF < avail) {
@@ -261,6 +268,9 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
       auto nodeBodyT = [&](auto exactTag, auto deferTag) -> bool {
         {
           GNode nd;
+          typedef uint32_t ProbeVec __attribute__((ext_vector_type(4)));
+          ProbeVec probeLoad = {0u, 0u, 0u, 0u};
+          if (!FIXED_TUNE && (tune.probe & 1u)) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(probeLoad) : "v"(node), "s"(sc.nodes) : "memory");
           // (uniform base + 32-bit byte offset: the load takes the scalar-base form, one shift instead of 64-bit address math)
           if (LDS_NODES && node < (ldsNodeCount << 5)) nd = *reinterpret_cast<const GNode*>(dynLds + node);
           else nd = *reinterpret_cast<const GNode*>(reinterpret_cast<const char*>(sc.nodes) + node);
@@ -302,6 +312,12 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
             }
           }
           const bool boxHit = !(t0 > t1);
+          if (!FIXED_TUNE && (tune.probe & 1u)) asm volatile("s_waitcnt vmcnt(0)" : "+v"(probeLoad) : : "memory");      // (the register is the load's until it has landed)
+          if (!FIXED_TUNE && (tune.probe & 2u)) {
+            float q0 = ax, q1 = bx, q2 = ay, q3 = by, q4 = az, q5 = bz, q6 = t0, q7 = t1;
+            asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\tv_mov_b32 %2, %2\n\tv_mov_b32 %3, %3\n\tv_mov_b32 %4, %4\n\tv_mov_b32 %5, %5\n\tv_mov_b32 %6, %6\n\tv_mov_b32 %7, %7"
+                         : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7));
+          }
           if (SPEC) {
             const bool isLeaf = node_is_leaf(nd);
             const uint32_t here = node >> 5;                       // (leaves[] is indexed by node)
@@ -457,6 +473,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
       if (STATS) { itS++; lnS += cS; }
       const unsigned long long tq1 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
       bool envRay = false;          // this lane's path ended in this SHADE step by escaping (slot mode)
+      bool pathEnd = false;
       uint32_t envSlot = 0;
       if (ph == PH_SHADE) {
         pathLoad();
@@ -510,7 +527,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
             envSlot = (uint32_t)q;
             if (!envRay) ex.u[q] = -1.f;
           } else { coldF(3) = coldF(3) + color.x; coldF(4) = coldF(4) + color.y; coldF(5) = coldF(5) + color.z; }
-          ++paths;
+          pathEnd = true;
           ++sample;
           const bool more = segd ? ((sample & segMask) != 0u && sample < spp) : (sample < spp);
           if (more) ph = PH_GEN;
@@ -553,11 +570,11 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
           if (FAST) fast_box_setup(o, inv, oi, slabPad);
           hit.t = kInf; hit.leaf = 0xFFFFFFFFu;
           { uint32_t seen; node = root_start(sc, o, seen) << 5; if (STATS) cs.nodes += seen; }
-          ++casts;
           ph = (numNodes > 0) ? PH_NODE : PH_SHADE;
         }
         pathStore();
       }
+      { const uint32_t ended = (uint32_t)__popcll(__ballot(pathEnd)); paths += ended; casts += cS - ended; }    // every SHADE lane either ends its path or casts again
       if (slots) {
         const unsigned long long mE = __ballot(envRay);
         if (mE) {
@@ -577,7 +594,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
             ex.u[envSlot] = theta * invPi;
             ex.v[envSlot] = phi * inv2Pi;
             ex.slotTp[3 * (size_t)envSlot] = tp.x; ex.slotTp[3 * (size_t)envSlot + 1] = tp.y; ex.slotTp[3 * (size_t)envSlot + 2] = tp.z;
-            ex.index[baseE + (uint32_t)__popcll(mE & ((1ull << lane) - 1ull))] = envSlot;
+            ex.index[baseE + lane_rank(mE)] = envSlot;
           }
         }
       }
@@ -610,14 +627,14 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
         if (FAST) fast_box_setup(o, inv, oi, slabPad);
         hit.t = kInf; hit.leaf = 0xFFFFFFFFu;
         { uint32_t seen; node = root_start(sc, o, seen) << 5; if (STATS) cs.nodes += seen; }
-        ++casts;
         ph = (numNodes > 0) ? PH_NODE : PH_SHADE;
         pathStore();
       }
+      casts += cG;
       if (STATS) tGen += __builtin_amdgcn_s_memtime() - tq2;
     }
   }
-  flush_stats(sc, casts, cs, paths);
+  flush_stats(sc, lane == 0 ? casts : 0u, cs, lane == 0 ? paths : 0u);
   if (STATS && lane == 0) {
     atomicAdd(&sc.counters[4], (unsigned long long)itN); atomicAdd(&sc.counters[5], (unsigned long long)lnN);
     atomicAdd(&sc.counters[6], (unsigned long long)itL); atomicAdd(&sc.counters[7], (unsigned long long)lnL);
