@@ -262,6 +262,8 @@ def main():
     if local_rank == 0:
         ge.build_cpu()
         ge.build_device()
+    else:
+        ge.wait_built()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     if world == 1 and args.gpus > 1 and args.launch == "group":
