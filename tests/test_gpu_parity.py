@@ -988,6 +988,35 @@ def test_launch_grids_follow_the_compute_unit_count(scenes):
         assert_streams_identical(frames[1], frames[0], "NIF render on a grid for 3 compute units")
 
 
+def test_work_units_fetch_coordinates_from_the_compact_copy_or_the_records(scenes):
+    """(pixel, segment) work units read the pixel's (row, col) from a compact copy of the stream gathered once per launch
+    (option "coords", default on) or, with the option off, from the 84-byte records as up to round 3: either way every
+    TraceResult byte is the oracle's - a segmented plain render, a ragged crop whose stream is not made of whole rows, and a
+    NIF render (slots), whose two settings must agree with each other."""
+    s = scenes["box"]
+    with _desc_restored(s.desc) as d:
+        d.set_image(150, 90, (131, 77, 7, 3)); d.samples_per_pixel = 200; d.path_trace = 1      # (crop: width, height, x, y)
+        want = s.init_ray_stream(); ol.path_trace_pixel_rng(d, want, 16)
+        for coords in (1, 0):
+            dev = irl.IpuScene(d).set_option("coords", coords)
+            got = s.init_ray_stream(); dev.run(got, irl.MODE_PATH_TRACE); dev.close()
+            assert_streams_identical(got, want, f"segmented render, coords={coords}")
+        with pytest.raises(irl.RaylibError):
+            irl.IpuScene(d).set_option("coords", 2)
+    sp = scenes["spheres"]
+    with _desc_restored(sp.desc) as d:
+        rng = np.random.default_rng(9)
+        ks, bs, relu = _nif_weights(rng, hidden=64, embed=12, layers=4)
+        d.set_image(80, 56); d.samples_per_pixel = 24; d.path_trace = 1
+        frames = []
+        for coords in (1, 0):
+            dev = irl.IpuScene(d).set_option("coords", coords)
+            dev.setNif(ks, bs, relu, 12, 3.43, np.array([-2.35, -2.26, -1.96], np.float32), True)
+            got = sp.init_ray_stream(); dev.run(got, irl.MODE_PATH_TRACE); dev.close()
+            frames.append(got)
+        assert_streams_identical(frames[1], frames[0], "NIF render, coords=0 against coords=1")
+
+
 def test_one_scene_on_two_streams_concurrently(scenes):
     """mi_render_device on two HIP streams of ONE scene: each stream owns its work counter and partial-sum buffer
     (LaunchSlot), so two segmented renders in flight together both equal the oracle."""

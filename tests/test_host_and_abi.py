@@ -344,3 +344,20 @@ def test_nif_activation_image_layout_is_conflict_free():
             for ks in range(12):
                 for mt in range(rows // 16):
                     assert xbyte(rows, 16 * mt + (lane & 15), 32 * ks + 8 * (lane >> 4)) == base + ks * rows * 64 + mt * 1024
+
+
+def test_builds_are_not_started_where_they_must_not_be(monkeypatch, tmp_path):
+    """MI_NO_BUILD=1 (profiled runs: a compiler child would be an exec after the profiler's preload initialised the GPU) turns a
+    stale binary into an error instead of a build, and the ranks of a multi-process job that do not build wait for the
+    building one (wait_built) - neither ever compiles."""
+    import __graft_entry__ as ge
+    ge.build_cpu()                                   # fresh by now (conftest built everything): a no-op
+    ge.wait_built(5)                                 # ... so the waiting ranks return at once
+    monkeypatch.setenv("MI_NO_BUILD", "1")
+    with pytest.raises(ge.StaleBinary):
+        ge._run(["true"])
+    monkeypatch.setattr(ge, "_stale", lambda *a, **k: True)
+    with pytest.raises(ge.StaleBinary):
+        ge.wait_built(0.3)
+    with pytest.raises(ge.StaleBinary):
+        ge.build_host()                              # stale + MI_NO_BUILD: refused, nothing is run
