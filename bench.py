@@ -400,7 +400,7 @@ def main():
     # this kernel is the rate at which a CU can serve its walk's dependent 32-byte node gathers. MI355X_MICROARCH.md has
     # no figure for that (LDS, L2, HBM and MFMA rates only), so it is MEASURED: csrc/probe/gather_probe.hip performs only
     # the gathers - two global_load_dwordx4 per lane at an index that depends on the node fetched before, a tree-shaped
-    # walk over THIS scene's node array, K1w's launch shape (256-thread workgroups, 5 per CU), as many of a wave's 64
+    # walk over THIS scene's node array, K1w's launch shape (256-thread workgroups, 6 per CU), as many of a wave's 64
     # lanes active as K1w's box-test turns have - and its rate (TA busy 0.99: profiles/r04_gather_probe_pmc.txt) is the
     # peak; `frac` = K1w's gathers per second / the probe's. In this run when the probe library is there, else from
     # profiles/r04_gather_probe.json.
@@ -442,7 +442,7 @@ def main():
             # (Anything else - a HIP error inside the probe, say - is a failure of this run and propagates.)
             gather["probe_error"] = f"{type(e).__name__}: {e}"
             pj = json.loads(GATHER_PROBE.read_text()) if GATHER_PROBE.exists() else {"rows": []}
-            row = min((r for r in pj["rows"] if r["path"].startswith("L1") and r["walk"] == "tree-shaped" and r["wg_per_cu"] == 5),
+            row = min((r for r in pj["rows"] if r["path"].startswith("L1") and r["walk"] == "tree-shaped" and r["wg_per_cu"] == 6),
                       key=lambda r: abs(r["active_lanes"] - node_lanes), default=None)
             if row:
                 gather["attainable_gathers_per_s"] = row["lane_gathers_per_s"]

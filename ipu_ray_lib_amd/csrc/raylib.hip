@@ -98,7 +98,8 @@ struct SceneOptions {
   uint32_t cus = 0;                // "cus": compute units the launch grids are sized for (0 = what the device reports)
   std::string why;                 // why the last set() returned false
   int poolWaves = 4;               // MI_RAYLIB_POOL_WAVES / "pool_waves": waves per workgroup of the path-pool kernel, 4 | 8 | 16 (400 | 800 | 1600 slots)
-  int wavesPerSimd = 5;            // MI_RAYLIB_WAVES / "waves": 4 = the 108-VGPR build of the default kernel, 6 = the 80-VGPR build (variants build)
+  int wavesPerSimd = 6;            // MI_RAYLIB_WAVES / "waves": 6 = the 80-VGPR build of the default kernel; variants build: 5 = the 96-VGPR build, 4 = the 4-wave build
+  bool mergeTurns = true;          // "merge" (variants build): 0 = SHADE and GEN as two turns, five waves - the default kernel up to round 3
   bool specLeaf = false;           // MI_RAYLIB_SPEC / "spec": lanes walk on past ONE pending primitive test (trace_wavefront.hpp, SPEC)
   bool tiles = true;               // MI_RAYLIB_NO_TILES / "tiles": walk row-structured streams in 8x8 pixel tiles
   size_t segBudgetKb = (size_t)8 * 1024 * 1024;   // MI_RAYLIB_SEG_BUDGET_KB / "seg_budget_kb": partial-sum buffer budget per launch
@@ -150,6 +151,7 @@ struct SceneOptions {
     }
     if (key == "waves") { if (!number(v, 4, 6, q)) return false; wavesPerSimd = (int)q; return true; }
     if (key == "spec") return flag01(v, specLeaf);
+    if (key == "merge") return flag01(v, mergeTurns);
 #else
     if (key == "kernel") {
       if (!number(v, 0, 3, q)) return false;
@@ -157,7 +159,8 @@ struct SceneOptions {
       kernelChoice = (int)q; return true;
     }
     if (key == "pool_waves" || key == "pool_tune" || key == "tune") { why = "not compiled into this library (the variants build, -DMI_RAYLIB_VARIANTS=1, has it)"; return false; }
-    if (key == "waves") { if (!number(v, 4, 5, q)) return false; if (q != 5) { why = "the 4-wave build is not compiled into this library (variants build)"; return false; } return true; }
+    if (key == "waves") { if (!number(v, 4, 6, q)) return false; if (q != 6) { why = "the 4- and 5-wave builds are not compiled into this library (variants build)"; return false; } return true; }
+    if (key == "merge") { bool b = true; if (!flag01(v, b)) return false; if (!b) { why = "the two-turn form is not compiled into this library (variants build)"; return false; } return true; }
     if (key == "spec") { bool b = false; if (!flag01(v, b)) return false; if (b) { why = "the speculative walk is not compiled into this library (variants build)"; return false; } return true; }
 #endif
     if (key == "cus") { if (!number(v, 0, 4096, q)) return false; cus = (uint32_t)q; return true; }
@@ -179,7 +182,7 @@ struct SceneOptions {
       if (!flag01(v, b)) return false;
       if (b && (fullStats || doubleFallback)) { why = "fast cannot be combined with full_stats or double_fallback"; return false; }
 #if MI_RAYLIB_VARIANTS
-      if (b && (kernelChoice != 1 || specLeaf || wavesPerSimd != 5 || !(tune == kDefaultTune))) { why = "fast is a build of the default kernel only (kernel 1, 5 waves, default weights, no spec)"; return false; }
+      if (b && (kernelChoice != 1 || specLeaf || wavesPerSimd != 6 || !mergeTurns || !(tune == kDefaultTune))) { why = "fast is a build of the default kernel only (kernel 1, 6 waves, one SHADE / GEN turn, default weights, no spec)"; return false; }
 #endif
       fast = b; return true;
     }
@@ -590,7 +593,7 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
       // the tolerance tier (never the default): FMA box and triangle tests. Plain, un-instrumented launches of the default kernel only;
       // mi_scene_set_option refuses the combinations it has no build for, a NIF render is refused here.
       if (!plain || STATS) throw ArgError("mi_render: the tolerance tier (option fast) has no NIF / instrumented build; clear the option for this render");
-      go(path_trace_wavefront_kernel<false, false, 256, 5, false, 0, true, false, true>);
+      go(path_trace_wavefront_kernel<false, false, 256, 6, false, 0, true, false, true>);
 #if MI_RAYLIB_VARIANTS
     } else if (S.opt.kernelChoice == 3 && S.ds.samplesPerPixel <= kPoolMaxSamples && S.ds.maxPathLength <= kPoolMaxBounces) {
       // path pool (trace_pool.hpp): persistent, exactly as many workgroups as stay resident; a workgroup of W waves
@@ -628,18 +631,25 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
       const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 1023) / 1024, S.cus());
       hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, ldsNodes, S.opt.tune, tileW, exs);
     } else if (S.opt.specLeaf) {
-      if (!STATS && S.opt.wavesPerSimd == 5) go(path_trace_wavefront_kernel<false, false, 256, 5, true>);
+      if (!STATS) go(path_trace_wavefront_kernel<false, false, 256, 5, true>);
       else go(path_trace_wavefront_kernel<STATS, false, 256, 4, true>);
-    } else if (!STATS && S.opt.wavesPerSimd == 5 && !(S.opt.tune == kDefaultTune)) {
-      go(path_trace_wavefront_kernel<false, false, 256, 5>);            // runtime weights (tune sweeps): 42 scalar spills, 4 % slower
-    } else if (!STATS && S.opt.wavesPerSimd == 6 && plain) {
-      go(path_trace_wavefront_kernel<false, false, 256, 6, false, 0, true>);   // the 80-VGPR build: six waves per SIMD
-#endif
+    } else if (!STATS && !(S.opt.tune == kDefaultTune)) {
+      // runtime weights (tune sweeps, knock-in probes): scalar spills, a few per cent slower than the compiled-in weights
+      if (S.opt.wavesPerSimd == 6) go(path_trace_wavefront_kernel<false, false, 256, 6>);
+      else go(path_trace_wavefront_kernel<false, false, 256, 5>);
+    } else if (!STATS && !S.opt.mergeTurns) {
+      // SHADE and GEN as two turns, five waves per SIMD: the default kernel up to round 3, kept for A/B and parity
+      if (plain) go(path_trace_wavefront_kernel<false, false, 256, 5, false, 0, true, false, false, false>);
+      else go(path_trace_wavefront_kernel<false, false, 256, 5, false, 1, true, false, false, false>);
     } else if (!STATS && S.opt.wavesPerSimd == 5) {
-      // the default path. 96-VGPR build, 5 waves per SIMD (+4.6 % on the box scene; 6 waves = 80 VGPRs: -19 %, its spills land
-      // in LEAF/SHADE); the default scheduling weights are compiled into the two instantiations (plain renders / NIF slots)
-      if (plain) go(path_trace_wavefront_kernel<false, false, 256, 5, false, 0, true>);
+      if (plain) go(path_trace_wavefront_kernel<false, false, 256, 5, false, 0, true>);        // the 96-VGPR build of today's form
       else go(path_trace_wavefront_kernel<false, false, 256, 5, false, 1, true>);
+#endif
+    } else if (!STATS && S.opt.wavesPerSimd == 6) {
+      // the default path: SHADE and GEN in one turn, 80 VGPRs without a spill, six waves per SIMD (profiles/r04_k1w_merged_turn_ab.txt);
+      // the default scheduling weights are compiled into the two instantiations (plain renders / NIF slots)
+      if (plain) go(path_trace_wavefront_kernel<false, false, 256, 6, false, 0, true>);
+      else go(path_trace_wavefront_kernel<false, false, 256, 6, false, 1, true>);
     } else {
       go(path_trace_wavefront_kernel<STATS, false, 256>);               // the instrumented build (and, in the variants build, option waves = 4)
     }

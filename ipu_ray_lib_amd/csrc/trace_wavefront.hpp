@@ -110,7 +110,7 @@ constexpr WaveTune kDefaultTune = {8, 16, 24, 48, 3, 4, 6, 1, 1, 40, 0};      //
 // DF: the reference's ALLOW_DOUBLE_FALLBACK=1 build of the triangle test (trace_kernels.hpp). FAST: the tolerance tier
 // (scene option "fast"): the box test as three pairs of FMAs on (plane, 1/d, -o/d), the triangle test contracted, no
 // literal NaN-exact fallback - results within a stated tolerance of the exact tier's, not bit-identical.
-template <bool STATS, bool LDS_NODES, int BLOCK, int WAVES_PER_SIMD = 4, bool SPEC = false, int SLOTS = 2, bool FIXED_TUNE = false, bool DF = false, bool FAST = false>
+template <bool STATS, bool LDS_NODES, int BLOCK, int WAVES_PER_SIMD = 4, bool SPEC = false, int SLOTS = 2, bool FIXED_TUNE = false, bool DF = false, bool FAST = false, bool MERGE = true>
 __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? WAVES_PER_SIMD : 1) path_trace_wavefront_kernel(DeviceScene sc, mi_trace_result* rays, uint32_t n,
                                                                    uint32_t* workCounter, uint32_t ldsNodeCount, WaveTune tuneArg, uint32_t tileStreamW, WaveExtras ex) {
   const WaveTune tune = FIXED_TUNE ? kDefaultTune : tuneArg;
@@ -249,7 +249,8 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
     {
       const uint32_t pT = cN + cL, pS = cS, pG = cG;
       const uint32_t wT = pT * 4u, wS = pS * tune.shadeAt, wG = pG * tune.genAt;
-      if (pT > 0 && wT >= max(wS, wG)) run = 0;
+      if (MERGE) run = (pT > 0 && wT >= wS + wG) ? 0 : 2;        // (one turn serves both: the weights add; the frame is flat in them, +-0.3 %)
+      else if (pT > 0 && wT >= max(wS, wG)) run = 0;
       else run = (wS >= wG) ? 2 : 3;
     }
     if (run == 0) {
@@ -468,6 +469,157 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
       }
       if (tune.prio == 1) __builtin_amdgcn_s_setprio(0); else if (tune.prio == 2) __builtin_amdgcn_s_setprio(1);
       if (STATS) tTrav += __builtin_amdgcn_s_memtime() - tq0;
+    } else if (MERGE) {
+      // ---------------- SHADE and GEN in ONE turn (MERGE, the default since round 4) ----------------
+      // A lane whose path ends with samples left draws its next camera ray in the same turn, lanes that wait in GEN (they come
+      // from FETCH) join, and the cast set-up (reciprocal direction, shear, root start) runs once for both populations: no GEN
+      // turns and their votes, one copy of the set-up code - the 80-VGPR build of this form has no spills, so six waves fit a
+      // SIMD and, unlike with the two-turn form, pay (profiles/r04_k1w_merged_turn_ab.txt: 368 -> 348 ms, with six waves 328).
+      if (STATS) { itS++; lnS += cS + cG; }
+      const unsigned long long tq1 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+      bool envRay = false, pathEnd = false, genNow = false, setup = false;
+      uint32_t envSlot = 0;
+      const bool wasShade = ph == PH_SHADE, wasGen = ph == PH_GEN;
+      if (wasShade || wasGen) pathLoad();
+      if (wasShade) {
+        bool terminated = false;
+        if (hit.leaf != 0xFFFFFFFFu) {
+          const GLeaf L = sc.leaves[hit.leaf];
+          hit.geomID = leaf_geom(L);
+          coldU(6) = hit.leaf; coldF(7) = hit.t;
+          o = o + d * hit.t;
+          nrm = hit_normal(sc, hit, o);
+          const mi_material mat = matsInLds ? matS[L.matIndex].m : sc.materials[L.matIndex];
+          const f3 albedo = mk(mat.albedo.x, mat.albedo.y, mat.albedo.z);
+          if (mat.emissive) color = color + tp * mk(mat.emission.x, mat.emission.y, mat.emission.z);
+          if (mat.type == 0) {
+            const float u1 = rng_uniform01(rng);
+            const float u2 = rng_uniform01(rng);
+            d = sample_diffuse(nrm, u1, u2, sinTbl);
+            tp = tp * albedo;
+          } else if (mat.type == 1) {
+            d = reflect_dir(d, nrm);
+            tp = tp * albedo;
+          } else if (mat.type == 2) {
+            const float u1 = rng_uniform01(rng);
+            f3 nd2;
+            const bool refracted = dielectric(d, nrm, mat.ior, u1, nd2);
+            d = nd2;
+            if (refracted) tp = tp * albedo;
+          } else {
+            const float qn = __builtin_nanf("");
+            coldF(3) = coldF(3) * qn; coldF(4) = coldF(4) * qn; coldF(5) = coldF(5) * qn;
+            oFlags |= MI_FLAG_ERROR;
+          }
+        } else {
+          coldF(7) = kInf;
+          oFlags |= MI_FLAG_ESCAPED;
+          terminated = true;
+        }
+        if (!terminated && bounce > sc.rouletteStartDepth) {
+          const float u1 = rng_uniform01(rng);
+          if (roulette_stop(u1, tp)) terminated = true;
+        }
+        bounce++;
+        if (bounce >= sc.maxPathLength) terminated = true;
+        if (terminated) {
+          const uint32_t pixNow = getPix();
+          mi_trace_result* res = rays + pixNow;
+          if (slots) {
+            const size_t q = (size_t)sample * n + pixNow;
+            ex.slotColor[3 * q] = color.x; ex.slotColor[3 * q + 1] = color.y; ex.slotColor[3 * q + 2] = color.z;
+            envRay = (oFlags & MI_FLAG_ESCAPED) != 0;
+            envSlot = (uint32_t)q;
+            if (!envRay) ex.u[q] = -1.f;
+          } else { coldF(3) = coldF(3) + color.x; coldF(4) = coldF(4) + color.y; coldF(5) = coldF(5) + color.z; }
+          pathEnd = true;
+          ++sample;
+          const bool more = segd ? ((sample & segMask) != 0u && sample < spp) : (sample < spp);
+          if (more) genNow = true;
+          else if (segd && sample < spp) {
+            if (!slots && ex.segPart) {
+              float* part = ex.segPart + 3 * ((size_t)(((sample - 1u) >> segShift) - ex.segBase) * n + pixNow);
+              part[0] = coldF(3); part[1] = coldF(4); part[2] = coldF(5);
+            }
+            ph = PH_FETCH;
+          } else {
+            if (!slots && ex.segPart) {
+              float* part = ex.segPart + 3 * ((size_t)(((sample - 1u) >> segShift) - ex.segBase) * n + pixNow);
+              part[0] = coldF(3); part[1] = coldF(4); part[2] = coldF(5);
+            } else
+            if (!slots) res->rgb = {coldF(3), coldF(4), coldF(5)};
+            uint32_t oPrim = MI_INVALID_PRIM, oGeom = MI_INVALID_GEOM;
+            const uint32_t lastLeaf = coldU(6);
+            if (lastLeaf != 0xFFFFFFFFu) { const GLeaf LL = sc.leaves[lastLeaf]; oPrim = LL.primID; oGeom = leaf_geom(LL); }
+            mi_hit_record hr;
+            hr.r.origin = {o.x, o.y, o.z}; hr.r.t_min = 0.f;
+            hr.r.direction = {d.x, d.y, d.z}; hr.r.t_max = coldF(7);
+            hr.prim_id = oPrim;
+            hr.normal = {nrm.x, nrm.y, nrm.z};
+            hr.throughput = {tp.x, tp.y, tp.z};
+            hr.geom_id = (uint16_t)oGeom; hr.flags = (uint16_t)oFlags;
+            res->h = hr;
+            ph = PH_FETCH;
+          }
+        } else {
+          o = offset_origin(o, d, nrm);
+          setup = true;
+        }
+      }
+      if (slots) {
+        const unsigned long long mE = __ballot(envRay);
+        if (mE) {
+          const uint32_t firstE = (uint32_t)__ffsll((long long)mE) - 1u;
+          uint32_t baseE = 0;
+          if (lane == firstE) baseE = atomicAdd(ex.count, (uint32_t)__popcll(mE));
+          baseE = __shfl(baseE, firstE);
+          if (envRay) {
+            const float twoPi = (float)(2.0 * 3.14159265358979323846264338327950288);
+            const float invPi = (float)(1.0 / 3.14159265358979323846264338327950288);
+            const float inv2Pi = (float)(1.0 / (2.0 * 3.14159265358979323846264338327950288));
+            const float theta = acosf(d.y);
+            float phi = atan2f(d.z, d.x) + ex.azimuthRotation;
+            if (phi < 0.f) phi += twoPi;
+            else if (phi > twoPi) phi -= twoPi;
+            ex.u[envSlot] = theta * invPi;
+            ex.v[envSlot] = phi * inv2Pi;
+            ex.slotTp[3 * (size_t)envSlot] = tp.x; ex.slotTp[3 * (size_t)envSlot + 1] = tp.y; ex.slotTp[3 * (size_t)envSlot + 2] = tp.z;
+            ex.index[baseE + lane_rank(mE)] = envSlot;
+          }
+        }
+      }
+      if (genNow || wasGen) {
+        prow = coldF(1); pcol = coldF(2);
+        float g0, g1;
+        rng_gauss2(rng, sinTbl, g0, g1);
+        const float jr = prow + sc.antiAliasScale * g0, jc = pcol + sc.antiAliasScale * g1;
+        d = pixel_to_ray_dir(jc, jr, sc.imageWidth, sc.imageHeight, sc.tanTheta);
+        o = mk(0.f, 0.f, 0.f);
+        nrm = mk(0.f, 0.f, 1.f);
+        coldU(6) = 0xFFFFFFFFu; coldF(7) = kInf;
+        oFlags = 0;
+        tp = mk(1.f, 1.f, 1.f);
+        color = mk(0.f, 0.f, 0.f);
+        bounce = 0;
+        o = offset_origin(o, d, nrm);
+        setup = true;
+      }
+      if (setup) {
+        if (FAST) { inv = fast_inverse(d); sh = make_shear_fast(d, inv); }
+        else {
+          inv = mk(1.f / d.x, 1.f / d.y, 1.f / d.z);
+          exactSlab = !(fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf && fabsf(o.x) < kInf && fabsf(o.y) < kInf && fabsf(o.z) < kInf);
+          sh = make_shear(d, inv);
+        }
+        if (FAST) fast_box_setup(o, inv, oi, slabPad);
+        hit.t = kInf; hit.leaf = 0xFFFFFFFFu;
+        { uint32_t seen; node = root_start(sc, o, seen) << 5; if (STATS) cs.nodes += seen; }
+        ph = (numNodes > 0) ? PH_NODE : PH_SHADE;
+      }
+      if (wasShade || wasGen) pathStore();
+      paths += (uint32_t)__popcll(__ballot(pathEnd));
+      casts += (uint32_t)__popcll(__ballot(setup));
+      if (STATS) tShade += __builtin_amdgcn_s_memtime() - tq1;
     } else if (run == 2) {
       // ---------------- SHADE: traversal of bounce `bounce` is complete ----------------
       if (STATS) { itS++; lnS += cS; }

@@ -204,13 +204,16 @@ def campaign(budget=240.0, seed=1, scale=1, max_cases=None):
         waves = str(rng.choice(["4", "5", "6"]))
         batch = int(rng.integers(1, 4000)) if rng.random() < 0.25 else 0
         df = int(rng.random() < 0.2)          # the reference's ALLOW_DOUBLE_FALLBACK=1 build, on both sides (Mesh.cpp:38-51)
+        merge = int(rng.integers(0, 4) != 0)  # one case in four: SHADE and GEN as two turns (the form of round 3)
         desc = (f"case {case} (seed {seed}): {what} {w}x{h} crop={crop} spp={spp} rngseed={d.rng_seed} aa={d.anti_alias_scale} "
-                f"len={d.max_path_length} roulette={d.roulette_start_depth} mode={mode} kernel={kernel} waves={waves} batch={batch} double_fallback={df}")
+                f"len={d.max_path_length} roulette={d.roulette_start_depth} mode={mode} kernel={kernel} waves={waves} merge={merge} batch={batch} double_fallback={df}")
         spec = int(rng.integers(0, 2))
         # the shipped library when the case draws its default path (or the nested-loop kernel), the variants build of the same
         # sources otherwise: both are under the campaign
-        use_variants = kernel not in ("0", "1") or waves != "5" or spec == 1
+        use_variants = kernel not in ("0", "1") or waves != "6" or spec == 1 or merge == 0
         dev = irl.IpuScene(d, variants=use_variants).set_option("kernel", kernel).set_option("waves", waves).set_option("spec", spec).set_option("double_fallback", df)
+        if use_variants:
+            dev.set_option("merge", merge)
         got = s.init_ray_stream()
         if rng.random() < 0.3:
             for k in "xyz":

@@ -105,10 +105,12 @@ def _scene_with_kernel(desc, kernel):
 
 
 def _with_kernel(dev, kernel):
-    """kernel strings: "0" | "1" | "1w4" | "1w6" | "1s" (speculative walk past a pending primitive test) | "2" | "3" | "3p8" | "3p16" (variant + waves per SIMD / waves per pool workgroup)"""
+    """kernel strings: "0" | "1" | "1w4" | "1w5" | "1m0" (SHADE and GEN as two turns, the default up to round 3) | "1s" (speculative walk past a pending primitive test) | "2" | "3" | "3p8" | "3p16" (variant + waves per SIMD / waves per pool workgroup)"""
     dev.set_option("kernel", kernel[0])
-    if kernel.endswith("w4") or kernel.endswith("w6"):
+    if kernel.endswith("w4") or kernel.endswith("w5"):
         dev.set_option("waves", kernel[-1])
+    if kernel.endswith("m0"):
+        dev.set_option("merge", 0)
     if kernel.endswith("s"):
         dev.set_option("spec", 1)
     if "p" in kernel:
@@ -116,12 +118,12 @@ def _with_kernel(dev, kernel):
     return dev
 
 
-@pytest.mark.parametrize("kernel", ["0", "1", "1w4", "1w6", "1s", "2", "3", "3p8", "3p16"])
+@pytest.mark.parametrize("kernel", ["0", "1", "1w4", "1w5", "1m0", "1s", "2", "3", "3p8", "3p16"])
 @pytest.mark.parametrize("name,size,spp", [("box-simple", 128, 32), ("box", 160, 24), ("spheres", 128, 32)])
 def test_path_trace_bit_exact(scenes, name, size, spp, kernel):
     """kernel 0 = nested-loop kernel, 1 = phase-scheduled persistent kernel, 2 = the same with the BVH
-    prefix staged in LDS, 3 = the path-pool kernel (workgroups of 4, 8 or 16 waves); 1 is built for 5 waves per SIMD
-    and, in the test build, for 4 and 6 ("1w4", "1w6"). All of them must reproduce the oracle bit for bit."""
+    prefix staged in LDS, 3 = the path-pool kernel (workgroups of 4, 8 or 16 waves); 1 is built for 6 waves per SIMD
+    and, in the test build, for 4 and 5 ("1w4", "1w5") and in its two-turn form of round 3 ("1m0"). All of them must reproduce the oracle bit for bit."""
     s = scenes[name]
     s.desc.set_image(size, size)
     s.desc.path_trace = 1
@@ -950,10 +952,10 @@ def test_scene_options_are_per_scene(scenes, monkeypatch):
     with pytest.raises(irl.RaylibError, match="unknown option"):
         plain.set_option("no_such_option", 1)
     # the shipped library carries the default path only: the measured-and-rejected kernel families are refused by name
-    for key, value in (("kernel", 2), ("kernel", 3), ("spec", 1), ("waves", 4), ("tune", "8,16,24"), ("pool_waves", 8), ("nif_shape", "r8"), ("nif_shape", "r8s")):
+    for key, value in (("kernel", 2), ("kernel", 3), ("spec", 1), ("waves", 4), ("waves", 5), ("merge", 0), ("tune", "8,16,24"), ("pool_waves", 8), ("nif_shape", "r8"), ("nif_shape", "r8s")):
         with pytest.raises(irl.RaylibError, match="not compiled into this library"):
             plain.set_option(key, value)
-    plain.set_option("kernel", 1).set_option("spec", 0).set_option("waves", 5)      # the defaults are accepted
+    plain.set_option("kernel", 1).set_option("spec", 0).set_option("waves", 6).set_option("merge", 1)      # the defaults are accepted
     assert b"+variants" in irl.device_lib(True).mi_version() and b"+variants" not in irl.device_lib().mi_version()
     plain.close(); probe.close(); other.close()
 

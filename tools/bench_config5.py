@@ -26,10 +26,13 @@ MEAN = np.array([-2.3514461517333984, -2.2660605907440186, -1.9648972749710083],
 MAXV = 3.4299468994140625
 
 
-def one_gpu(d, scene, ks, bs, relu, steps, warmup, device=0):
+def one_gpu(d, scene, ks, bs, relu, steps, warmup, device=0, opts=""):
     d1 = irl.SceneDesc.from_buffer_copy(d); d1.device = device
     torch.cuda.set_device(device)
-    dev = irl.IpuScene(d1).set_option("nif_timing", 1)
+    # (--opts key=value[:key=value]: scene options of the variants build, for same-box A/B of the trace kernel's forms)
+    dev = irl.IpuScene(d1, variants=bool(opts)).set_option("nif_timing", 1)
+    for kv in filter(None, opts.split(":")):
+        dev.set_option(*kv.split("=", 1))
     dev.setNif(ks, bs, relu, 12, MAXV, MEAN, True)
     rays = scene.init_ray_stream(); n = rays.size
     t = torch.from_numpy(rays.view(np.uint8).reshape(n, irl.TRACE_RESULT.itemsize).copy()).cuda()
@@ -65,6 +68,7 @@ def main():
     ap.add_argument("--rehearsal", action="store_true", help="allow repeated ordinals in --devices (replicas sharing a GPU)")
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--opts", default="", help="N = 1: scene options of the variants build, key=value[:key=value] (e.g. merge=0)")
     a = ap.parse_args()
     s = irl.HostScene.builtin("monkey"); d = s.desc
     d.set_image(a.size, a.size); d.samples_per_pixel = a.spp; d.path_trace = 1
@@ -73,8 +77,8 @@ def main():
     out = {"workload": f"monkey + NIF {a.size}x{a.size} x {a.spp} spp (BASELINE config 5{'' if (a.size, a.spp) == (1440, 4000) else ', reduced'})",
            "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup}
     if a.gpus == 1:
-        r = one_gpu(d, s, ks, bs, relu, a.steps, a.warmup)
-        out.update({"launch": "single", "ms_per_frame": r["ms_per_frame"], "ms_per_sample": r["ms_per_frame"] / a.spp,
+        r = one_gpu(d, s, ks, bs, relu, a.steps, a.warmup, opts=a.opts)
+        out.update({"launch": "single", "opts": a.opts, "ms_per_frame": r["ms_per_frame"], "ms_per_sample": r["ms_per_frame"] / a.spp,
                     "mlp_share": r["mlp_ms_per_frame"] / r["ms_per_frame"], "mlp_ms_per_frame": r["mlp_ms_per_frame"],
                     "mlp_launches_per_frame": r["mlp_launches_per_frame"], "paths_per_s": r["paths"] / (r["ms_per_frame"] * 1e-3),
                     "casts_per_path": r["casts"] / max(r["paths"], 1), "escaped_fraction_last_sample": r["escaped_fraction_last_sample"],

@@ -74,7 +74,7 @@ for name in ("tree35", "uni35", "tree64", "lds35"):
     probe_lines.append(f"probe {name}: {PROBE[name]['avg_ms']:.3f} ms, clock {PROBE[name]['clock_ghz']:.2f} GHz, lane-gathers {PROBE[name]['lane_gathers_per_clk_per_cu']:.3f} /clk/CU, "
                        f"L1 accesses {PROBE[name]['l1_accesses_per_clk_per_cu']:.3f} /clk/CU ({PROBE[name]['l1_accesses_per_lane_gather']:.2f} per lane-gather), TA busy {PROBE[name]['ta_busy']:.3f}, L1 hit rate {PROBE[name]['l1_hit_rate']:.4f}")
 if PROBE:
-    (DST / f"{TAG}_gather_probe_pmc.json").write_text(json.dumps({"source_commit": COMMIT, "note": "rocprofv3 --pmc passes of tools/gather_probe.py --only path,walk,lanes,5 (tools/prof_gather_probe.sh); lanes in the set's name", "sets": PROBE}, indent=1))
+    (DST / f"{TAG}_gather_probe_pmc.json").write_text(json.dumps({"source_commit": COMMIT, "note": "rocprofv3 --pmc passes of tools/gather_probe.py --only path,walk,lanes,6 (tools/prof_gather_probe.sh); lanes in the set's name", "sets": PROBE}, indent=1))
     (DST / f"{TAG}_gather_probe_pmc.txt").write_text("\n".join(probe_lines) + "\n")
 
 bench = json.loads((SRC / "bench.json").read_text())
@@ -107,7 +107,7 @@ for tag, kern in (("c2", "path_trace_wavefront_kernel<false"), ("c3", "path_trac
         casts = bench["value"] * bench["ms_per_step"] * 1e-3
         summary = {
             "workload": ["box", 1440, 1440, 1000, 1],
-            "kernel": "path_trace_wavefront_kernel<false,false,256,5,false,0,true> (+ segment_combine_kernel, not included)",
+            "kernel": "path_trace_wavefront_kernel<false,false,256,6,false,0,true> (SHADE and GEN in one turn; + segment_combine_kernel, not included)",
             "source": f"rocprofv3 --pmc, one group per pass (tools/prof_{TAG}.sh: python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras; profiles/{TAG}_c2_pmc.csv), mean over the timed launches of a pass",
             "source_commit": COMMIT,
             "l1_accesses_per_clk_per_cu": c["TCP_TOTAL_CACHE_ACCESSES_sum"] / CUS / cycles,

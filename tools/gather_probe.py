@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Node-gather roof of K1w's access shape: builds csrc/probe/gather_probe.hip and runs it on the
 built-in scene's device node array for N = 16 / 35 / 64 active lanes, the L1, all-LDS and mixed data paths, uniform and
-walk-shaped index sequences, at K1w's occupancy (5 workgroups of 256 threads per CU) and at 4 and 8.
+walk-shaped index sequences, at K1w's occupancy (6 workgroups of 256 threads per CU; 5 up to round 3) and at 5, 4 and 8.
 
     python tools/gather_probe.py [--scene box] [--out profiles/r03_gather_probe.json] [--quick]
 
@@ -29,7 +29,7 @@ def build():
     return lib
 
 
-def measure(lib, nodes, path, walk, lanes, wg=5, steps=20000, reps=3, lds_nodes=512):
+def measure(lib, nodes, path, walk, lanes, wg=6, steps=20000, reps=3, lds_nodes=512):
     """One configuration: (average launch ms, lane-gathers per second chip-wide)."""
     blocks = C.c_uint32()
     ms = lib.gp_run(nodes.ctypes.data, nodes.size, path, walk, steps, lanes, lds_nodes if path else 1, wg, reps, C.byref(blocks))
@@ -75,7 +75,7 @@ def main():
         p, w, l, g = [int(x) for x in args.only.split(",")]
         cfgs = [(p, w, l, g, 512)]
     else:
-        for wg in ((5,) if args.quick else (5, 4, 8)):
+        for wg in ((6,) if args.quick else (6, 5, 4, 8)):
             for walk in (1, 0):
                 for path in (0, 1, 2):
                     for lanes in (16, 35, 64):

@@ -33,7 +33,7 @@ def main():
     for spec in a.specs:
         # (options of the kernel families outside the shipped library select the variants build of the same sources)
         opts = dict(kv.split("=", 1) for kv in spec.split(":") if "=" in kv)
-        dev = irl.IpuScene(d, variants=(opts.get("kernel", "1") not in ("0", "1") or opts.get("spec", "0") != "0" or opts.get("waves", "5") != "5"
+        dev = irl.IpuScene(d, variants=(opts.get("kernel", "1") not in ("0", "1") or opts.get("spec", "0") != "0" or opts.get("waves", "6") != "6" or opts.get("merge", "1") != "1"
                                         or any(k in opts for k in ("tune", "pool_waves", "pool_tune"))))
         for kv in spec.split(":"):
             k, v = kv.split("=", 1)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 passes over one configuration of the gather probe (tools/gather_probe.py --only path,walk,lanes,wg):
 # kernel trace + the counters K1w's record quotes (TCP accesses, TA busy, the clock). Run on the GPU box:
-#   tools/prof_gather_probe.sh gpurun_out/<dir> 0,1,35,5
+#   tools/prof_gather_probe.sh gpurun_out/<dir> 0,1,35,6
 out=$1; cfg=$2
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 mkdir -p $R/$out

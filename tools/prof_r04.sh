@@ -47,12 +47,12 @@ python3 $R/tools/bench_config5.py 4000 > $OUT/c5_full.json 2> $OUT/c5_full.err |
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5/stats -o st -- python3 $R/tools/bench_config5.py 512 > $OUT/c5_stats.log 2>&1 || echo "c5 stats failed"
 # the node-gather microbenchmark (the measured roof K1w's record quotes): the table, and PMC passes at saturation
 python3 $R/tools/gather_probe.py --out $OUT/gather_probe.json > $OUT/gather_probe.txt 2>&1 || echo "gather probe failed"
-for cfg in "tree35 0,1,35,5" "uni35 0,0,35,5" "tree64 0,1,64,5" "lds35 1,1,35,5"; do
+for cfg in "tree35 0,1,35,6" "uni35 0,0,35,6" "tree64 0,1,64,6" "lds35 1,1,35,6"; do
   set -- $cfg
   $R/tools/prof_gather_probe.sh gpurun_out/prof_r04/probe_$1 $2
 done
 # the tolerance tier and the double-fallback variant next to the default kernel, same box
-python3 $R/tools/k_sweep.py --reps 3 kernel=1 fast=1 double_fallback=1 cus=64 kernel=1 fast=1 > $OUT/variants.txt 2>&1 || echo "variants failed"
+python3 $R/tools/k_sweep.py --reps 3 kernel=1 merge=0 waves=5 fast=1 double_fallback=1 cus=64 kernel=1 merge=0 waves=5 fast=1 > $OUT/variants.txt 2>&1 || echo "variants failed"
 # the un-profiled bench line of the same build
 python3 $R/bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err || echo "bench failed"
 echo done
