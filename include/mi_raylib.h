@@ -212,11 +212,13 @@ int mi_scene_set_ray_batch(mi_scene* scene, size_t rays_per_batch);
  * by the MI_RAYLIB_* environment variables as they stand when the scene is created, then by this call. Keys and the
  * values each accepts (anything else: MI_ERR_INVALID_ARG, the option keeps its value):
  *   "kernel"        0 | 1 | 2 | 3   nested-loop / phase-scheduled (default) / phase-scheduled + LDS-staged nodes / path pool
- *   "waves"         4 | 5 | 6       waves per SIMD the default kernel is built for (5: the 96-VGPR build, the default; 4 and 6 - the 80-VGPR
- *                                   build, measured no faster - only in the variants build)
+ *   "waves"         4 | 5 | 6       waves per SIMD the default kernel is built for (6: the 80-VGPR build, the default; 5 - the 96-VGPR build -
+ *                                   and 4 only in the variants build)
+ *   "merge"         0 | 1           kernel 1: SHADE and GEN served by one turn (1, the default) or by two, at five waves per SIMD - the
+ *                                   default kernel up to round 3 (0: variants build only)
  *   "spec"          0 | 1           kernel 1: lanes walk on past ONE pending primitive test
  *   "full_stats"    0 | 1           instrumented kernels: node / leaf-test counters, phase occupancy
- *   "tune"          "leafAt,shadeAt,genAt[,burst,keep8,dbl,maxExtra(<=7),leafThenNode,prio,leafP]"   scheduling weights of kernel 1
+ *   "tune"          "leafAt,shadeAt,genAt[,burst,keep8,dbl,maxExtra(<=7),leafThenNode,prio,leafP,probe]"   scheduling weights of kernel 1
  *   "pool_waves"    4 | 8 | 16      kernel 3: waves per workgroup
  *   "pool_tune"     "leafAt,burst,retireAt,refillMin,shadeW,genW[,dbl,maxExtra,leafThenNode,prio]"
  *   "tiles"         0 | 1           walk row-structured streams in 8x8 pixel tiles

@@ -66,7 +66,7 @@ for name in ("tree35", "uni35", "tree64", "lds35"):
     k = [r for r in csv.DictReader(open(st_f)) if "gather_probe" in r["Name"]][0]
     c = {n: sum(v[1:]) / max(len(v[1:]), 1) for n, v in agg.items()}
     cyc = c["GRBM_GUI_ACTIVE"] / 8.0
-    lanes = int(name[-2:]); gathers = 256 * 5 * 4 * lanes * 20000
+    lanes = int(name[-2:]); gathers = 256 * 6 * 4 * lanes * 20000        # 256 CUs x 6 resident workgroups (K1w's launch shape; tools/prof_r04.sh) x 4 waves x lanes x steps
     PROBE[name] = {"avg_ms": float(k["AverageNs"]) / 1e6, "clock_ghz": cyc / (float(k["AverageNs"]) * 1e-9) / 1e9,
                    "l1_accesses_per_clk_per_cu": c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0) / CUS / cyc, "ta_busy": c.get("TA_TA_BUSY_sum", 0) / CUS / cyc,
                    "lane_gathers_per_clk_per_cu": gathers / CUS / cyc, "l1_accesses_per_lane_gather": c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0) / gathers,
