@@ -108,6 +108,8 @@ struct SceneOptions {
   uint32_t nifShape = 0;           // MI_RAYLIB_NIF_SHAPE / "nif_shape": 0 = w6 (default), 1 = t6, 2 = t4; 4 = r8, 5 = r8s (K3r, nif_regs_kernel.hpp: measured slower, selectable)
   bool coords = true;              // "coords": (pixel, segment) atoms read the pixel coordinates from a compact copy of the stream's (u, v)
   bool nifOverlap = true;          // "nif_overlap": NIF renders trace sample batch b + 1 beside the MLP of batch b (two slot sets, second stream)
+  uint32_t nifTraceWgs = 1;        // "nif_trace_wgs": a NIF render's trace launch that runs beside the previous batch's MLP gets at most this many workgroups per
+                                   // compute unit (0 = all that stay resident): the MLP is the longer of the two and its workgroups need the room (profiles/r04_nif_overlap_ab.txt)
   bool nifTiming = false;          // "nif_timing": HIP events round every MLP launch of a NIF render (mi_get_nif_timing)
   // the two options that select ARITHMETIC (every other option leaves every result bit alone):
   bool doubleFallback = false;     // "double_fallback": the reference's ALLOW_DOUBLE_FALLBACK=1 build (CMakeLists.txt:13,34-41; Mesh.cpp:38-51), bit-exact to the oracle in that mode
@@ -170,6 +172,7 @@ struct SceneOptions {
     if (key == "pin") return flag01(v, pin);
     if (key == "nif_timing") return flag01(v, nifTiming);
     if (key == "nif_overlap") return flag01(v, nifOverlap);
+    if (key == "nif_trace_wgs") { if (!number(v, 0, 16, q)) return false; nifTraceWgs = (uint32_t)q; return true; }
     if (key == "coords") return flag01(v, coords);
     if (key == "double_fallback") {
       bool b = doubleFallback;
@@ -213,7 +216,8 @@ struct SceneOptions {
                                          {"MI_RAYLIB_SEG_BUDGET_KB", "seg_budget_kb"}, {"MI_RAYLIB_NIF_SPL", "nif_spl"}, {"MI_RAYLIB_PIN", "pin"},
                                          {"MI_RAYLIB_NIF_SHAPE", "nif_shape"}, {"MI_RAYLIB_TUNE", "tune"},
                                          {"MI_RAYLIB_POOL_TUNE", "pool_tune"}, {"MI_RAYLIB_POOL_WAVES", "pool_waves"}, {"MI_RAYLIB_CUS", "cus"},
-                                         {"MI_RAYLIB_NIF_OVERLAP", "nif_overlap"}, {"MI_RAYLIB_COORDS", "coords"}};
+                                         {"MI_RAYLIB_NIF_OVERLAP", "nif_overlap"}, {"MI_RAYLIB_COORDS", "coords"},
+                                         {"MI_RAYLIB_NIF_TRACE_WGS", "nif_trace_wgs"}};
     // (an unparsable environment value is ignored: the option keeps its default. The two options that select ARITHMETIC,
     // double_fallback and fast, are deliberately not in this list: a process that says "bit-exact" must not change tier
     // because of a variable somebody exported)
@@ -523,7 +527,7 @@ constexpr uint32_t kLdsBudgetBytes = 160 * 1024 - 2048 - 23 * 1024 * 4;     // 1
 constexpr uint64_t kMaxWorkItems = 0xFFFFFFFFull - ((uint64_t)1 << 22);
 
 template <bool STATS>
-void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStream_t stream, const WaveExtras& ex = WaveExtras{}) {
+void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStream_t stream, const WaveExtras& ex = WaveExtras{}, uint32_t wgCap = 0) {
   LaunchSlot& slot = S.slotFor(stream);
   uint32_t* workCounter = slot.d_workCounter;
   // Streams are walked in 8x8 pixel tiles of window-width rows (a whole window, a batch of it, or one rank's
@@ -577,7 +581,9 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
     // Grid: persistent workgroups, as many as stay resident (compute units x workgroups per unit, asked of the runtime for
     // the kernel about to be launched and remembered per scene), never more than the launch has work for.
     auto grid = [&](auto kern, uint32_t threads, size_t ldsBytes) {
-      return (uint32_t)std::min<uint64_t>((items + threads - 1) / threads, (uint64_t)S.cus() * S.residentBlocks(reinterpret_cast<const void*>(kern), (int)threads, ldsBytes));
+      uint32_t perUnit = S.residentBlocks(reinterpret_cast<const void*>(kern), (int)threads, ldsBytes);
+      if (wgCap) perUnit = std::min(perUnit, wgCap);      // (NIF renders: a trace launch that runs beside the previous batch's MLP)
+      return (uint32_t)std::min<uint64_t>((items + threads - 1) / threads, (uint64_t)S.cus() * perUnit);
     };
     auto go = [&](auto kern) {
 #if MI_RAYLIB_VARIANTS
@@ -711,8 +717,9 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
           ex.sampleCount = sc; ex.segments = (sc + segLen - 1) / segLen; ex.segBase = s0 / segLen;     // (pixel, segment) atoms
           ex.u = q.u; ex.v = q.v; ex.slotColor = q.color; ex.slotTp = q.tp;
           ex.index = q.index; ex.count = q.count; ex.azimuthRotation = radians;
-          if (S.opt.fullStats) launchWavefront<true>(S, d_rays, cnt, stream, ex);
-          else launchWavefront<false>(S, d_rays, cnt, stream, ex);
+          const uint32_t wgCap = (two && b > 0) ? S.opt.nifTraceWgs : 0u;       // batch 0 has the device to itself
+          if (S.opt.fullStats) launchWavefront<true>(S, d_rays, cnt, stream, ex, wgCap);
+          else launchWavefront<false>(S, d_rays, cnt, stream, ex, wgCap);
           if (two) { HIP_CHECK(hipEventRecord(q.traced, stream)); HIP_CHECK(hipStreamWaitEvent(mlpStream, q.traced, 0)); }
           std::pair<hipEvent_t, hipEvent_t> tm{nullptr, nullptr};
           if (S.opt.nifTiming) { HIP_CHECK(hipEventCreate(&tm.first)); HIP_CHECK(hipEventCreate(&tm.second)); S.nifTimes.push_back(tm); HIP_CHECK(hipEventRecord(tm.first, mlpStream)); }

@@ -30,7 +30,7 @@ def one_gpu(d, scene, ks, bs, relu, steps, warmup, device=0, opts=""):
     d1 = irl.SceneDesc.from_buffer_copy(d); d1.device = device
     torch.cuda.set_device(device)
     # (--opts key=value[:key=value]: scene options of the variants build, for same-box A/B of the trace kernel's forms)
-    dev = irl.IpuScene(d1, variants=bool(opts)).set_option("nif_timing", 1)
+    dev = irl.IpuScene(d1, variants=bool(opts) and any(k.split("=")[0] in ("merge", "waves", "kernel", "spec", "tune") for k in opts.split(":"))).set_option("nif_timing", 1)
     for kv in filter(None, opts.split(":")):
         dev.set_option(*kv.split("=", 1))
     dev.setNif(ks, bs, relu, 12, MAXV, MEAN, True)
