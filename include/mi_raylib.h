@@ -229,7 +229,7 @@ int mi_scene_set_ray_batch(mi_scene* scene, size_t rays_per_batch);
  *   "pin"           0 | 1           page-lock the caller's stream for the duration of mi_render
  *   "nif_overlap"   0 | 1           NIF renders trace sample batch b + 1 beside the MLP of batch b (two slot sets, a second stream; default 1)
  *   "nif_trace_wgs" 0..16           with nif_overlap: workgroups per compute unit of a trace launch that runs beside the previous batch's MLP
- *                                   (default 1; 0 = all that stay resident)
+ *                                   (0 = all that stay resident, the default)
  *   "nif_timing"    0 | 1           bracket every MLP launch of a NIF render with HIP events (mi_get_nif_timing)
  *   "coords"        0 | 1           (pixel, segment) work units read the pixel's (u, v) from a compact copy of the stream gathered once
  *                                   per launch, not from the 84-byte record (default 1: a third of the HBM traffic)

@@ -108,8 +108,9 @@ struct SceneOptions {
   uint32_t nifShape = 0;           // MI_RAYLIB_NIF_SHAPE / "nif_shape": 0 = w6 (default), 1 = t6, 2 = t4; 4 = r8, 5 = r8s (K3r, nif_regs_kernel.hpp: measured slower, selectable)
   bool coords = true;              // "coords": (pixel, segment) atoms read the pixel coordinates from a compact copy of the stream's (u, v)
   bool nifOverlap = true;          // "nif_overlap": NIF renders trace sample batch b + 1 beside the MLP of batch b (two slot sets, second stream)
-  uint32_t nifTraceWgs = 1;        // "nif_trace_wgs": a NIF render's trace launch that runs beside the previous batch's MLP gets at most this many workgroups per
-                                   // compute unit (0 = all that stay resident): the MLP is the longer of the two and its workgroups need the room (profiles/r04_nif_overlap_ab.txt)
+  uint32_t nifTraceWgs = 0;        // "nif_trace_wgs": a NIF render's trace launch that runs beside the previous batch's MLP gets at most this many workgroups per
+                                   // compute unit (0 = all that stay resident, the default: a cap of 1 paid 3 % while the trace launch queued behind its list
+                                   // counter, and costs 0.7 % since it does not: profiles/r04_nif_overlap_ab.txt, r04_nif_trace_ab.txt)
   bool nifTiming = false;          // "nif_timing": HIP events round every MLP launch of a NIF render (mi_get_nif_timing)
   // the two options that select ARITHMETIC (every other option leaves every result bit alone):
   bool doubleFallback = false;     // "double_fallback": the reference's ALLOW_DOUBLE_FALLBACK=1 build (CMakeLists.txt:13,34-41; Mesh.cpp:38-51), bit-exact to the oracle in that mode
@@ -476,6 +477,9 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
 // more samples per launch mean more (pixel, segment) atoms per lane and fewer launch tails: 128 by default, fewer
 // when n x samples x 44 B would pass 16 GiB (never less than one segment). Option "nif_spl" overrides (1..128,
 // rounded up to whole segments).
+// slot-mode (NIF) launches: at most this many workgroups, each wave of which may leave kEnvChunk - 1 padded entries in the escaped-slot list
+constexpr uint32_t kMaxSlotWorkgroups = 4096;
+
 void ensureScratch(mi_scene& S, size_t n) {
   {
     const uint32_t asked = S.opt.nifSamplesPerLaunch;
@@ -510,7 +514,8 @@ void ensureScratch(mi_scene& S, size_t n) {
     HIP_CHECK(hipMalloc(&q.bgr, 3 * slots * sizeof(float)));
     HIP_CHECK(hipMalloc(&q.color, 3 * slots * sizeof(float)));
     HIP_CHECK(hipMalloc(&q.tp, 3 * slots * sizeof(float)));
-    HIP_CHECK(hipMalloc(&q.index, slots * sizeof(uint32_t)));
+    // (every wave of a slot-mode launch pads the list to a whole chunk: trace_wavefront.hpp pushEscaped, kMaxSlotWorkgroups)
+    HIP_CHECK(hipMalloc(&q.index, (slots + (size_t)kMaxSlotWorkgroups * 4u * kEnvChunk) * sizeof(uint32_t)));
     if (!q.count) HIP_CHECK(hipMalloc(&q.count, sizeof(uint32_t)));
     if (!q.traced) HIP_CHECK(hipEventCreateWithFlags(&q.traced, hipEventDisableTiming));
     if (!q.done) HIP_CHECK(hipEventCreateWithFlags(&q.done, hipEventDisableTiming));
@@ -583,7 +588,9 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
     auto grid = [&](auto kern, uint32_t threads, size_t ldsBytes) {
       uint32_t perUnit = S.residentBlocks(reinterpret_cast<const void*>(kern), (int)threads, ldsBytes);
       if (wgCap) perUnit = std::min(perUnit, wgCap);      // (NIF renders: a trace launch that runs beside the previous batch's MLP)
-      return (uint32_t)std::min<uint64_t>((items + threads - 1) / threads, (uint64_t)S.cus() * perUnit);
+      uint64_t wgs = std::min<uint64_t>((items + threads - 1) / threads, (uint64_t)S.cus() * perUnit);
+      if (!plain) wgs = std::min<uint64_t>(wgs, kMaxSlotWorkgroups);      // (the escaped-slot list has padding for that many)
+      return (uint32_t)wgs;
     };
     auto go = [&](auto kern) {
 #if MI_RAYLIB_VARIANTS

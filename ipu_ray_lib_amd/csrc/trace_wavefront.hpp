@@ -106,6 +106,9 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// entries of the escaped-slot list a wave reserves at a time (slot mode; the host sizes the list for the padding: raylib.hip)
+constexpr uint32_t kEnvChunk = 256;
+
 constexpr WaveTune kDefaultTune = {8, 16, 24, 48, 3, 4, 6, 1, 1, 40, 0};      // re-swept on the round-3 kernel on two scenes (profiles/r03_kernel_ab.txt): a cheaper box test favours one more of them per vote
 // DF: the reference's ALLOW_DOUBLE_FALLBACK=1 build of the triangle test (trace_kernels.hpp). FAST: the tolerance tier
 // (scene option "fast"): the box test as three pairs of FMAs on (plane, 1/d, -o/d), the triangle test contracted, no
@@ -189,6 +192,44 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
   // STATS only: per-wave phase executions and the lanes that were active in them (wave-uniform values)
   uint32_t itN = 0, itL = 0, itS = 0, itG = 0, lnN = 0, lnL = 0, lnS = 0, lnG = 0;
   unsigned long long tTrav = 0, tShade = 0, tGen = 0, tLoop0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;   // STATS: shader cycles per phase
+
+  // Slot mode: the escaped paths of a SHADE turn append their slots to the list the MLP consumes (ex.index, ex.count), with
+  // their environment coordinates (PreProcessEscapedRays, codelets/TraceCodelets.cpp:321-358, same arithmetic as
+  // escaped_uv_kernel) and throughput. The wave takes room in the list kEnvChunk entries at a time: one atomic on the ONE
+  // counter every wave of the launch shares per chunk, not per turn - in an open scene nearly every SHADE turn has an escape,
+  // and the waves queued behind that address (profiles/r04_nif_trace_ab.txt). What a wave has left of its last chunk when it
+  // runs out of work is padded with a slot it wrote before: the MLP evaluates that ray once more into the same slot, which
+  // changes nothing (each row's result depends on the row alone).
+  uint32_t envNext = 0, envEnd = 0, envFill = 0;      // wave-uniform
+  auto pushEscaped = [&](bool envRay, uint32_t envSlot) {
+    const unsigned long long mE = __ballot(envRay);
+    if (!mE) return;
+    const uint32_t firstE = (uint32_t)__ffsll((long long)mE) - 1u;
+    const uint32_t nE = (uint32_t)__popcll(mE), room = envEnd - envNext;
+    uint32_t fresh = 0;
+    if (nE > room) {
+      uint32_t b = 0;
+      if (lane == firstE) b = atomicAdd(ex.count, kEnvChunk);
+      fresh = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(b, firstE));
+    }
+    if (envRay) {
+      const float twoPi = (float)(2.0 * 3.14159265358979323846264338327950288);
+      const float invPi = (float)(1.0 / 3.14159265358979323846264338327950288);
+      const float inv2Pi = (float)(1.0 / (2.0 * 3.14159265358979323846264338327950288));
+      const float theta = acosf(d.y);
+      float phi = atan2f(d.z, d.x) + ex.azimuthRotation;
+      if (phi < 0.f) phi += twoPi;
+      else if (phi > twoPi) phi -= twoPi;
+      ex.u[envSlot] = theta * invPi;
+      ex.v[envSlot] = phi * inv2Pi;
+      ex.slotTp[3 * (size_t)envSlot] = tp.x; ex.slotTp[3 * (size_t)envSlot + 1] = tp.y; ex.slotTp[3 * (size_t)envSlot + 2] = tp.z;
+      const uint32_t r = lane_rank(mE);
+      ex.index[r < room ? envNext + r : fresh + (r - room)] = envSlot;      // (the old chunk is filled to its end first)
+    }
+    envFill = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(envSlot, firstE));
+    if (nE > room) { envNext = fresh + (nE - room); envEnd = fresh + kEnvChunk; }
+    else envNext += nE;
+  };
 
   for (;;) {
     // ---------------- FETCH: cheap, always served first ----------------
@@ -566,28 +607,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
           setup = true;
         }
       }
-      if (slots) {
-        const unsigned long long mE = __ballot(envRay);
-        if (mE) {
-          const uint32_t firstE = (uint32_t)__ffsll((long long)mE) - 1u;
-          uint32_t baseE = 0;
-          if (lane == firstE) baseE = atomicAdd(ex.count, (uint32_t)__popcll(mE));
-          baseE = __shfl(baseE, firstE);
-          if (envRay) {
-            const float twoPi = (float)(2.0 * 3.14159265358979323846264338327950288);
-            const float invPi = (float)(1.0 / 3.14159265358979323846264338327950288);
-            const float inv2Pi = (float)(1.0 / (2.0 * 3.14159265358979323846264338327950288));
-            const float theta = acosf(d.y);
-            float phi = atan2f(d.z, d.x) + ex.azimuthRotation;
-            if (phi < 0.f) phi += twoPi;
-            else if (phi > twoPi) phi -= twoPi;
-            ex.u[envSlot] = theta * invPi;
-            ex.v[envSlot] = phi * inv2Pi;
-            ex.slotTp[3 * (size_t)envSlot] = tp.x; ex.slotTp[3 * (size_t)envSlot + 1] = tp.y; ex.slotTp[3 * (size_t)envSlot + 2] = tp.z;
-            ex.index[baseE + lane_rank(mE)] = envSlot;
-          }
-        }
-      }
+      if (slots) pushEscaped(envRay, envSlot);
       if (genNow || wasGen) {
         prow = coldF(1); pcol = coldF(2);
         float g0, g1;
@@ -727,29 +747,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
         pathStore();
       }
       { const uint32_t ended = (uint32_t)__popcll(__ballot(pathEnd)); paths += ended; casts += cS - ended; }    // every SHADE lane either ends its path or casts again
-      if (slots) {
-        const unsigned long long mE = __ballot(envRay);
-        if (mE) {
-          const uint32_t firstE = (uint32_t)__ffsll((long long)mE) - 1u;
-          uint32_t baseE = 0;
-          if (lane == firstE) baseE = atomicAdd(ex.count, (uint32_t)__popcll(mE));
-          baseE = __shfl(baseE, firstE);
-          if (envRay) {
-            // PreProcessEscapedRays (codelets/TraceCodelets.cpp:321-358), same arithmetic as escaped_uv_kernel
-            const float twoPi = (float)(2.0 * 3.14159265358979323846264338327950288);
-            const float invPi = (float)(1.0 / 3.14159265358979323846264338327950288);
-            const float inv2Pi = (float)(1.0 / (2.0 * 3.14159265358979323846264338327950288));
-            const float theta = acosf(d.y);
-            float phi = atan2f(d.z, d.x) + ex.azimuthRotation;
-            if (phi < 0.f) phi += twoPi;
-            else if (phi > twoPi) phi -= twoPi;
-            ex.u[envSlot] = theta * invPi;
-            ex.v[envSlot] = phi * inv2Pi;
-            ex.slotTp[3 * (size_t)envSlot] = tp.x; ex.slotTp[3 * (size_t)envSlot + 1] = tp.y; ex.slotTp[3 * (size_t)envSlot + 2] = tp.z;
-            ex.index[baseE + lane_rank(mE)] = envSlot;
-          }
-        }
-      }
+      if (slots) pushEscaped(envRay, envSlot);
       if (STATS) tShade += __builtin_amdgcn_s_memtime() - tq1;
     } else {
       // ---------------- GEN: camera ray of the next sample ----------------
@@ -786,6 +784,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
       if (STATS) tGen += __builtin_amdgcn_s_memtime() - tq2;
     }
   }
+  if (slots) for (uint32_t k = envNext + lane; k < envEnd; k += 64u) ex.index[k] = envFill;      // the rest of the wave's last chunk
   flush_stats(sc, lane == 0 ? casts : 0u, cs, lane == 0 ? paths : 0u);
   if (STATS && lane == 0) {
     atomicAdd(&sc.counters[4], (unsigned long long)itN); atomicAdd(&sc.counters[5], (unsigned long long)lnN);
