@@ -530,7 +530,10 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
           coldU(6) = hit.leaf; coldF(7) = hit.t;
           o = o + d * hit.t;
           nrm = hit_normal(sc, hit, o);
-          const mi_material mat = matsInLds ? matS[L.matIndex].m : sc.materials[L.matIndex];
+          // (two loads under a wave-uniform branch: as a select of the two addresses hipcc made FLAT loads of it, which go through the
+          // texture addresser as well as the LDS and wait on both counters)
+          mi_material mat;
+          if (matsInLds) { mat = matS[L.matIndex].m; asm volatile("" ::: "memory"); } else mat = sc.materials[L.matIndex];      // (the empty asm keeps the two loads apart)
           const f3 albedo = mk(mat.albedo.x, mat.albedo.y, mat.albedo.z);
           if (mat.emissive) color = color + tp * mk(mat.emission.x, mat.emission.y, mat.emission.z);
           if (mat.type == 0) {
@@ -656,7 +659,8 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
           coldU(6) = hit.leaf; coldF(7) = hit.t;
           o = o + d * hit.t;                                          // updateHit, Render.hpp:15-23
           nrm = hit_normal(sc, hit, o);
-          const mi_material mat = matsInLds ? matS[L.matIndex].m : sc.materials[L.matIndex];           // = materials[matIDs[geomID]]
+          mi_material mat;                                                                              // = materials[matIDs[geomID]]
+          if (matsInLds) { mat = matS[L.matIndex].m; asm volatile("" ::: "memory"); } else mat = sc.materials[L.matIndex];      // (the empty asm keeps the two loads apart)
           const f3 albedo = mk(mat.albedo.x, mat.albedo.y, mat.albedo.z);
           if (mat.emissive) color = color + tp * mk(mat.emission.x, mat.emission.y, mat.emission.z);
           if (mat.type == 0) {
