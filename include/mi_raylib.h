@@ -212,8 +212,8 @@ int mi_scene_set_ray_batch(mi_scene* scene, size_t rays_per_batch);
  * by the MI_RAYLIB_* environment variables as they stand when the scene is created, then by this call. Keys and the
  * values each accepts (anything else: MI_ERR_INVALID_ARG, the option keeps its value):
  *   "kernel"        0 | 1 | 2 | 3   nested-loop / phase-scheduled (default) / phase-scheduled + LDS-staged nodes / path pool
- *   "waves"         4 | 5 | 6       waves per SIMD the default kernel is built for (6: the 80-VGPR build, the default; 5 - the 96-VGPR build -
- *                                   and 4 only in the variants build)
+ *   "waves"         4 | 5 | 6 | 7   waves per SIMD the default kernel is built for (6: the 80-VGPR build, the default; 5 - the 96-VGPR build -,
+ *                                   4 and 7 - 72 VGPRs, 21 words of LDS per lane, measured 1 % slower - only in the variants build)
  *   "merge"         0 | 1           kernel 1: SHADE and GEN served by one turn (1, the default) or by two, at five waves per SIMD - the
  *                                   default kernel up to round 3 (0: variants build only)
  *   "spec"          0 | 1           kernel 1: lanes walk on past ONE pending primitive test

@@ -152,7 +152,7 @@ struct SceneOptions {
       poolTune = {a, b, c ? c : 1, d ? d : 1, e, f, db ? db : 65, mx, ln, pr};
       return true;
     }
-    if (key == "waves") { if (!number(v, 4, 6, q)) return false; wavesPerSimd = (int)q; return true; }
+    if (key == "waves") { if (!number(v, 4, 7, q)) return false; wavesPerSimd = (int)q; return true; }
     if (key == "spec") return flag01(v, specLeaf);
     if (key == "merge") return flag01(v, mergeTurns);
 #else
@@ -162,7 +162,7 @@ struct SceneOptions {
       kernelChoice = (int)q; return true;
     }
     if (key == "pool_waves" || key == "pool_tune" || key == "tune") { why = "not compiled into this library (the variants build, -DMI_RAYLIB_VARIANTS=1, has it)"; return false; }
-    if (key == "waves") { if (!number(v, 4, 6, q)) return false; if (q != 6) { why = "the 4- and 5-wave builds are not compiled into this library (variants build)"; return false; } return true; }
+    if (key == "waves") { if (!number(v, 4, 7, q)) return false; if (q != 6) { why = "the 4-, 5- and 7-wave builds are not compiled into this library (variants build)"; return false; } return true; }
     if (key == "merge") { bool b = true; if (!flag01(v, b)) return false; if (!b) { why = "the two-turn form is not compiled into this library (variants build)"; return false; } return true; }
     if (key == "spec") { bool b = false; if (!flag01(v, b)) return false; if (b) { why = "the speculative walk is not compiled into this library (variants build)"; return false; } return true; }
 #endif
@@ -654,6 +654,8 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
       // SHADE and GEN as two turns, five waves per SIMD: the default kernel up to round 3, kept for A/B and parity
       if (plain) go(path_trace_wavefront_kernel<false, false, 256, 5, false, 0, true, false, false, false>);
       else go(path_trace_wavefront_kernel<false, false, 256, 5, false, 1, true, false, false, false>);
+    } else if (!STATS && S.opt.wavesPerSimd == 7 && plain) {
+      go(path_trace_wavefront_kernel<false, false, 256, 7, false, 0, true>);                   // 72 VGPRs, 21 words of LDS per lane: seven waves per SIMD
     } else if (!STATS && S.opt.wavesPerSimd == 5) {
       if (plain) go(path_trace_wavefront_kernel<false, false, 256, 5, false, 0, true>);        // the 96-VGPR build of today's form
       else go(path_trace_wavefront_kernel<false, false, 256, 5, false, 1, true>);

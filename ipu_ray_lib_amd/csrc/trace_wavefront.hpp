@@ -169,9 +169,15 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
   // Cold per-lane state lives in LDS (23 dwords per lane, [word][thread] so a wave's accesses are conflict-free): the
   // pixel's stream index (0), its (row, col) (1, 2) and its running rgb sum (3..5) are touched once per path or per
   // pixel, and holding them in VGPRs made the 96-register build spill inside the traversal loop.
-  __shared__ uint32_t coldLds[23 * BLOCK];   // + the last hit's leaf and distance (6, 7) + the path state (8..22)
-  auto coldU = [&](uint32_t w) -> uint32_t& { return coldLds[w * BLOCK + threadIdx.x]; };
-  auto coldF = [&](uint32_t w) -> float& { return reinterpret_cast<float*>(coldLds)[w * BLOCK + threadIdx.x]; };
+  // A build for seven waves per SIMD must fit seven workgroups' LDS into a compute unit: it keeps 21 words, not 23 - the pixel's
+  // (row, col) (1, 2) are fetched again from the stream's compact copy by every GEN instead (8 bytes, an L2 hit: the lane's 64
+  // samples of one (pixel, segment) unit read the same address).
+  constexpr bool kCoordsFromStream = WAVES_PER_SIMD >= 7;
+  constexpr uint32_t kColdWords = kCoordsFromStream ? 21u : 23u;
+  __shared__ uint32_t coldLds[kColdWords * BLOCK];   // + the last hit's leaf and distance (6, 7) + the path state (8..22)
+  auto coldU = [&](uint32_t w) -> uint32_t& { return coldLds[((kCoordsFromStream && w > 2u) ? w - 2u : w) * BLOCK + threadIdx.x]; };
+  auto coldF = [&](uint32_t w) -> float& { return reinterpret_cast<float*>(coldLds)[((kCoordsFromStream && w > 2u) ? w - 2u : w) * BLOCK + threadIdx.x]; };
+
   auto getPix = [&]() -> uint32_t { return coldU(0); };
   // Path state that only SHADE / GEN / FETCH touch - the RNG, radiance, throughput, normal, bounce and sample
   // counters - is loaded at the top of those phases and stored at their end, so it holds no registers while the
@@ -265,7 +271,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
           const mi_trace_result* res = rays + entry;
           if (ex.coords) { const float2 pc = ex.coords[entry]; prow = pc.x; pcol = pc.y; }
           else { prow = res->u; pcol = res->v; }
-          coldU(0) = entry; coldF(1) = prow; coldF(2) = pcol;
+          coldU(0) = entry; if (!kCoordsFromStream) { coldF(1) = prow; coldF(2) = pcol; }
           if (seg == 0) { coldF(3) = res->rgb.x; coldF(4) = res->rgb.y; coldF(5) = res->rgb.z; }
           else { coldF(3) = 0.f; coldF(4) = 0.f; coldF(5) = 0.f; }           // a later segment's own partial sum
           rng_seed_pixel_segment(rng, sc.rngSeed, prow, pcol, seg);
@@ -612,7 +618,10 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
       }
       if (slots) pushEscaped(envRay, envSlot);
       if (genNow || wasGen) {
-        prow = coldF(1); pcol = coldF(2);
+        if constexpr (kCoordsFromStream) {
+          const uint32_t e = coldU(0);
+          if (ex.coords) { const float2 pc = ex.coords[e]; prow = pc.x; pcol = pc.y; } else { prow = rays[e].u; pcol = rays[e].v; }
+        } else { prow = coldF(1); pcol = coldF(2); }
         float g0, g1;
         rng_gauss2(rng, sinTbl, g0, g1);
         const float jr = prow + sc.antiAliasScale * g0, jc = pcol + sc.antiAliasScale * g1;
@@ -759,7 +768,10 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
       const unsigned long long tq2 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
       if (ph == PH_GEN) {
         pathLoad();
-        prow = coldF(1); pcol = coldF(2);
+        if constexpr (kCoordsFromStream) {
+          const uint32_t e = coldU(0);
+          if (ex.coords) { const float2 pc = ex.coords[e]; prow = pc.x; pcol = pc.y; } else { prow = rays[e].u; pcol = rays[e].v; }
+        } else { prow = coldF(1); pcol = coldF(2); }
         float g0, g1;
         rng_gauss2(rng, sinTbl, g0, g1);
         const float jr = prow + sc.antiAliasScale * g0, jc = pcol + sc.antiAliasScale * g1;

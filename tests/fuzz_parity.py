@@ -201,7 +201,7 @@ def campaign(budget=240.0, seed=1, scale=1, max_cases=None):
         mode = irl.MODE_PATH_TRACE if rng.random() < 0.8 else irl.MODE_SHADOW_TRACE
         d.path_trace = 1 if mode == irl.MODE_PATH_TRACE else 0
         kernel = str(rng.choice(["0", "1", "1", "3", "3", "2"]))
-        waves = str(rng.choice(["4", "5", "6"]))
+        waves = str(rng.choice(["4", "5", "6", "7"]))
         batch = int(rng.integers(1, 4000)) if rng.random() < 0.25 else 0
         df = int(rng.random() < 0.2)          # the reference's ALLOW_DOUBLE_FALLBACK=1 build, on both sides (Mesh.cpp:38-51)
         merge = int(rng.integers(0, 4) != 0)  # one case in four: SHADE and GEN as two turns (the form of round 3)

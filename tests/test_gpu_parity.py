@@ -105,9 +105,9 @@ def _scene_with_kernel(desc, kernel):
 
 
 def _with_kernel(dev, kernel):
-    """kernel strings: "0" | "1" | "1w4" | "1w5" | "1m0" (SHADE and GEN as two turns, the default up to round 3) | "1s" (speculative walk past a pending primitive test) | "2" | "3" | "3p8" | "3p16" (variant + waves per SIMD / waves per pool workgroup)"""
+    """kernel strings: "0" | "1" | "1w4" | "1w5" | "1w7" | "1m0" (SHADE and GEN as two turns, the default up to round 3) | "1s" (speculative walk past a pending primitive test) | "2" | "3" | "3p8" | "3p16" (variant + waves per SIMD / waves per pool workgroup)"""
     dev.set_option("kernel", kernel[0])
-    if kernel.endswith("w4") or kernel.endswith("w5"):
+    if kernel[-2:] in ("w4", "w5", "w7"):
         dev.set_option("waves", kernel[-1])
     if kernel.endswith("m0"):
         dev.set_option("merge", 0)
@@ -118,12 +118,12 @@ def _with_kernel(dev, kernel):
     return dev
 
 
-@pytest.mark.parametrize("kernel", ["0", "1", "1w4", "1w5", "1m0", "1s", "2", "3", "3p8", "3p16"])
+@pytest.mark.parametrize("kernel", ["0", "1", "1w4", "1w5", "1w7", "1m0", "1s", "2", "3", "3p8", "3p16"])
 @pytest.mark.parametrize("name,size,spp", [("box-simple", 128, 32), ("box", 160, 24), ("spheres", 128, 32)])
 def test_path_trace_bit_exact(scenes, name, size, spp, kernel):
     """kernel 0 = nested-loop kernel, 1 = phase-scheduled persistent kernel, 2 = the same with the BVH
     prefix staged in LDS, 3 = the path-pool kernel (workgroups of 4, 8 or 16 waves); 1 is built for 6 waves per SIMD
-    and, in the test build, for 4 and 5 ("1w4", "1w5") and in its two-turn form of round 3 ("1m0"). All of them must reproduce the oracle bit for bit."""
+    and, in the test build, for 4, 5 and 7 ("1w4", "1w5", "1w7") and in its two-turn form of round 3 ("1m0"). All of them must reproduce the oracle bit for bit."""
     s = scenes[name]
     s.desc.set_image(size, size)
     s.desc.path_trace = 1
