@@ -9,12 +9,14 @@
 //     GEN   next sample's camera ray                          (codelets/TraceCodelets.cpp:142-164)
 //     FETCH work unit finished: write it back, take another one from the global work counter
 // and each loop iteration the wave votes (ballot + popcount, scalar) and runs the phase most of its
-// lanes are waiting in. A lane that finishes a path immediately starts its next sample, a lane that
+// lanes are waiting in (SHADE and GEN are served by ONE turn: template parameter MERGE). A lane that
+// finishes a path starts its next sample in the turn that ended the path, a lane that
 // finishes a work unit - a 4- to 64-sample segment of a pixel (ray_math.h) - pulls a new one, so no lane
 // idles until the frame runs out of work; units are small on purpose, the drain at the end of a frame is paid
-// per unit. The kernel is bound by the latency of each wave's dependent chain (node load -> box test -> vote),
-// so the scheduling below is about few, short chains: several box tests per vote, whole 8x8 tiles per wave,
-// cold state in LDS so that five waves fit a SIMD. Each lane
+// per unit. The kernel is bound by instruction issue over half-empty waves and by the texture addresser that serves the
+// node gathers, so the scheduling below is about few, short chains and few instructions: several
+// box tests per vote, whole 8x8 tiles per wave, one copy of the cast set-up, cold state in LDS so that six waves fit a
+// SIMD without a spill. Each lane
 // still performs exactly the reference's sequence of operations for its rays, in the reference's
 // order, with the same arithmetic — only the interleaving between lanes changes — so results stay
 // bit-identical to the nested-loop kernel and to the CPU oracle.
