@@ -349,6 +349,14 @@ def main():
         elapsed = float(tmax[0])
     total_casts, total_paths = float(tot[1]), float(tot[2])
 
+    # N > 1: one more gather behind the timed region (a collective: every rank takes part), so that rank 0 can check the
+    # GATHERED frame - dealing, every rank's render and the collective - against the oracle
+    final_frame = None
+    if dist is not None and not args.no_cpu_baseline:
+        final_frame = gather()
+        if final_frame is not None:
+            final_frame = final_frame.cpu().numpy()
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -520,6 +528,30 @@ def main():
         fd.close(); del f_rays
 
     rc = 0
+    if final_frame is not None:
+        # ---------------- N > 1: parity of the gathered frame (rgb is what the gather moves) ----------------
+        import oracle_lib
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        cores = max(1, min(cores, 16))
+        stride = max(1, (width * height) // 1009)
+        flat = np.arange(0, width * height, stride)
+        rr, cc = flat // width, flat % width
+        want = make_stream(irl, rr, cc)
+        tp = time.perf_counter()
+        for _ in range(frames_rendered):
+            oracle_lib.path_trace_pixel_rng(d, want, cores)
+        got_rgb = np.ascontiguousarray(final_frame[rr, cc]).astype(np.float32)
+        want_rgb = np.stack([want["rgb"][k] for k in "xyz"], 1).astype(np.float32)
+        bad = int((got_rgb.view(np.uint32) != want_rgb.view(np.uint32)).any(axis=1).sum())
+        out["parity_checked_pixels"] = int(flat.size)
+        out["parity_mismatches"] = bad
+        out["parity_note"] = (f"every {stride}th pixel of the frame gathered on rank 0 after {frames_rendered} accumulated frames x {args.spp} spp: rgb, "
+                              f"bit for bit, vs oracle/ray_oracle.c ({time.perf_counter() - tp:.1f} s); the other 72 bytes of a TraceResult stay on their rank")
+        if bad:
+            rc = 1
     if not args.no_cpu_baseline and world == 1:
         import oracle_lib
         try:
