@@ -218,6 +218,8 @@ __device__ __forceinline__ void sincos_half_phase(float p, float& sn, float& cs)
 //   * the epilogue's ds_write_b64 (16 consecutive lanes = 16 rays, one column) is 2-way: 8 LDS cycles against the 6
 //     the instruction needs anyway (row-major with 8-bank row offsets it was 4-way: SQ_LDS_BANK_CONFLICT = 12 extra
 //     cycles per store).
+constexpr uint32_t kNifGenerations = 64;      // workgroups launched per resident slot (nif_launch_mlp)
+
 template <uint32_t ROWS>
 __device__ __forceinline__ uint32_t nif_x_byte(uint32_t ray, uint32_t col) {
   const uint32_t sw = (0x78u >> (2u * ((ray >> 2) & 3u))) & 3u;            // S = {0, 2, 3, 1}, two bits each: 0b01'11'10'00
@@ -628,10 +630,15 @@ inline void nif_launch_mlp(const NifDevice& nif, const float* u, const float* v,
 #if MI_NIF_STAMPS
     if (getenv("MI_NIF_DIAG_ONE_WG")) lds = kNifMaxLdsBytes;   // diagnostic: one workgroup per CU, i.e. one wave per SIMD for the 4-wave shape
 #endif
-    // grid-stride: four generations of the workgroups that stay resident (two per compute unit for the 4-wave shape - the LDS
-    // image sets that -, one for the 8-wave shapes), so a workgroup that finishes early leaves its slot to a waiting one
+    // grid-stride: kNifGenerations times the workgroups that stay resident (two per compute unit for the 4-wave shape - the LDS
+    // image sets that -, one for the 8-wave shapes). A workgroup is the unit the hardware balances: with 4 generations the 1440^2
+    // launch's workgroups ran 10 or 11 passes of 96 rays each and the last quarter of the chip's slots idled through the last
+    // pass; with 64 a workgroup runs one or two passes, a slot that comes free takes the next, and beside a trace launch
+    // (NIF renders) the two kernels' workgroups interleave finely: K3 alone -1.3 % (1.837 -> 1.813 ms), config 5 -4.5 %
+    // (profiles/r04_nif_generations_ab.txt). MI_NIF_GENERATIONS overrides the constant for such measurements.
+    static const uint32_t generations = [] { const char* e = getenv("MI_NIF_GENERATIONS"); const int g = e ? atoi(e) : 0; return (uint32_t)(g >= 1 && g <= 4096 ? g : kNifGenerations); }();
     uint32_t blocks = (numRows + rowsPerPass - 1) / rowsPerPass;
-    const uint32_t cap = numCUs * (threads == 256 ? 2u : 1u) * 4u;
+    const uint32_t cap = numCUs * (threads == 256 ? 2u : 1u) * generations;
     if (blocks > cap) blocks = cap;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNifMaxLdsBytes);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, nif.p, nif.d_weights, u, v, idx, countPtr, numRows, bgrOut, rays, scatter);
