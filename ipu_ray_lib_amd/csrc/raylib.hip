@@ -289,6 +289,7 @@ struct mi_scene {
 
   ~mi_scene() {
     (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();      // nothing of this scene's may still be in flight (device renders are asynchronous) when its buffers go
     for (void* p : allocations) (void)hipFree(p);
     if (d_rng) (void)hipFree(d_rng);
     freeNifSlots();
