@@ -1503,4 +1503,15 @@ def _fast_tier_within_its_stated_tolerance(scenes):
     ra = np.stack([a["rgb"][k] for k in "xyz"], 1); rb = np.stack([b["rgb"][k] for k in "xyz"], 1)
     assert np.allclose(ra.sum(0), rb.sum(0), rtol=2e-3), (ra.sum(0), rb.sum(0))
     exact.close(); fast.close()
+    # pixel by pixel: both tiers draw the same random numbers, so a pixel only differs where one of its 256 paths took
+    # another turn at a knife edge. Most pixels are the exact tier's bit for bit (measured 0.82), and what the others
+    # differ by is far below the image's own Monte-Carlo noise: the mean squared difference between the tiers is a few
+    # per cent (measured 2.2 %) of the one between two seeds of the EXACT tier.
+    assert np.mean((ra == rb).all(1)) >= 0.7, np.mean((ra == rb).all(1))
+    seed0 = int(d.rng_seed); d.rng_seed = seed0 + 1
+    other = irl.IpuScene(d); c = s.init_ray_stream(); other.run(c, irl.MODE_PATH_TRACE); other.close()
+    d.rng_seed = seed0
+    rc = np.stack([c["rgb"][k] for k in "xyz"], 1)
+    mse_tier, mse_seed = float(np.mean((ra - rb) ** 2)), float(np.mean((ra - rc) ** 2))
+    assert mse_tier <= 0.06 * mse_seed, (mse_tier, mse_seed)
     d.set_image(96, 64); d.samples_per_pixel = 5
