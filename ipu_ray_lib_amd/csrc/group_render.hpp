@@ -349,8 +349,9 @@ extern "C" {
 int mi_group_create(const mi_scene_desc* desc, const int32_t* devices, uint32_t num_replicas, int32_t transport, mi_group** out) {
   if (!desc || !devices || !out || num_replicas == 0 || num_replicas > 64) { g_err = "mi_group_create: bad argument (1..64 replicas)"; return MI_ERR_INVALID_ARG; }
   *out = nullptr;
-  mi_group* G = new mi_group;
+  mi_group* G = nullptr;
   const int rc = guarded([&] {
+    G = new mi_group;
     std::map<int, int> rankOf;
     for (uint32_t r = 0; r < num_replicas; ++r) {
       mi_scene_desc d = *desc;

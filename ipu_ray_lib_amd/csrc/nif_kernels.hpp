@@ -609,7 +609,8 @@ inline void nif_regs_launch(const NifRegsDevice& nr, const float* u, const float
 // network shapes it covers - measured 6 % (r8) and 15 % (r8s) SLOWER than w6 (profiles/r04_k3r_attempt.txt), so never the default
 // and compiled into the variants build only; a network it does not cover runs w6
 inline void nif_launch_mlp(const NifDevice& nif, const float* u, const float* v, const uint32_t* idx, const uint32_t* countPtr,
-                           uint32_t numRows, float* bgrOut, mi_trace_result* rays, hipStream_t stream, bool scatter = false, uint32_t shape = 0, uint32_t numCUs = 256) {
+                           uint32_t numRows, float* bgrOut, mi_trace_result* rays, hipStream_t stream, bool scatter = false, uint32_t shape = 0, uint32_t numCUs = 256,
+                           uint32_t generations = kNifGenerations) {
   if (numRows == 0) return;
 #if MI_RAYLIB_VARIANTS
   if (shape >= 4 && nif.regs.ok) { nif_regs_launch(nif.regs, u, v, idx, countPtr, numRows, bgrOut, rays, stream, scatter, numCUs, shape == 5 ? 0u : 1u); return; }
@@ -635,12 +636,12 @@ inline void nif_launch_mlp(const NifDevice& nif, const float* u, const float* v,
     // launch's workgroups ran 10 or 11 passes of 96 rays each and the last quarter of the chip's slots idled through the last
     // pass; with 64 a workgroup runs one or two passes, a slot that comes free takes the next, and beside a trace launch
     // (NIF renders) the two kernels' workgroups interleave finely: K3 alone -1.3 % (1.837 -> 1.813 ms), config 5 -4.5 %
-    // (profiles/r04_nif_generations_ab.txt). MI_NIF_GENERATIONS overrides the constant for such measurements.
-    static const uint32_t generations = [] { const char* e = getenv("MI_NIF_GENERATIONS"); const int g = e ? atoi(e) : 0; return (uint32_t)(g >= 1 && g <= 4096 ? g : kNifGenerations); }();
+    // (profiles/r04_nif_generations_ab.txt). Scene option "nif_generations" overrides the constant for such measurements.
     uint32_t blocks = (numRows + rowsPerPass - 1) / rowsPerPass;
     const uint32_t cap = numCUs * (threads == 256 ? 2u : 1u) * generations;
     if (blocks > cap) blocks = cap;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNifMaxLdsBytes);
+    if (const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNifMaxLdsBytes); e != hipSuccess)
+      throw std::runtime_error(std::string("NIF: hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, nif.p, nif.d_weights, u, v, idx, countPtr, numRows, bgrOut, rays, scatter);
   };
   if (mt == 6 && rg == 1) {
@@ -703,21 +704,22 @@ __global__ void __launch_bounds__(256) nif_segment_roll_kernel(mi_trace_result* 
 }
 
 // mi_nif_infer_device: every row is evaluated (no compaction)
-inline void nif_infer(NifDevice& nif, const float* d_u, const float* d_v, float* d_bgr, size_t n, size_t maxBatch, hipStream_t stream, uint32_t shape = 0, uint32_t numCUs = 256) {
+inline void nif_infer(NifDevice& nif, const float* d_u, const float* d_v, float* d_bgr, size_t n, size_t maxBatch, hipStream_t stream, uint32_t shape = 0, uint32_t numCUs = 256,
+                      uint32_t generations = kNifGenerations) {
   const size_t chunk = maxBatch ? maxBatch : n;
   for (size_t off = 0; off < n; off += chunk) {
     const size_t cnt = (n - off < chunk) ? (n - off) : chunk;
-    nif_launch_mlp(nif, d_u + off, d_v + off, nullptr, nullptr, (uint32_t)cnt, d_bgr + 3 * off, nullptr, stream, false, shape, numCUs);
+    nif_launch_mlp(nif, d_u + off, d_v + off, nullptr, nullptr, (uint32_t)cnt, d_bgr + 3 * off, nullptr, stream, false, shape, numCUs, generations);
   }
 }
 
 // One sample's environment pass over the whole ray stream (src/IpuScene.cpp:571-583)
 inline void nif_env_pass(NifDevice& nif, mi_trace_result* d_rays, uint32_t n, float azimuthRadians, float* d_u, float* d_v,
-                         float* d_bgr, size_t /*maxBatch*/, hipStream_t stream, uint32_t shape = 0, uint32_t numCUs = 256) {
+                         float* d_bgr, size_t /*maxBatch*/, hipStream_t stream, uint32_t shape = 0, uint32_t numCUs = 256, uint32_t generations = kNifGenerations) {
   nif.ensureIndex(n);
   (void)hipMemsetAsync(nif.d_count, 0, sizeof(uint32_t), stream);
   hipLaunchKernelGGL(escaped_uv_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_rays, n, azimuthRadians, d_u, d_v, nif.d_index, nif.d_count);
-  nif_launch_mlp(nif, d_u, d_v, nif.d_index, nif.d_count, n, nullptr, d_rays, stream, false, shape, numCUs);
+  nif_launch_mlp(nif, d_u, d_v, nif.d_index, nif.d_count, n, nullptr, d_rays, stream, false, shape, numCUs, generations);
 }
 
 }  // namespace mi

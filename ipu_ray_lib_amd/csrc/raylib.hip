@@ -64,6 +64,9 @@ int guarded(F&& f) {
   catch (const ArgError& e) { g_err = e.what(); return MI_ERR_INVALID_ARG; }
   catch (const DeviceError& e) { g_err = e.what(); return MI_ERR_DEVICE; }
   catch (const std::exception& e) { g_err = e.what(); return MI_ERR_DEVICE; }
+  // nothing crosses the C ABI (include/ipu_utils.hpp:590-595: an error becomes a status, never a crash): whatever else a
+  // callback or a library below us throws is reported like a device error
+  catch (...) { g_err = "unknown exception (not derived from std::exception)"; return MI_ERR_DEVICE; }
 }
 
 template <class T>
@@ -112,6 +115,9 @@ struct SceneOptions {
                                    // compute unit (0 = all that stay resident, the default: a cap of 1 paid 3 % while the trace launch queued behind its list
                                    // counter, and costs 0.7 % since it does not: profiles/r04_nif_overlap_ab.txt, r04_nif_trace_ab.txt)
   bool nifTiming = false;          // "nif_timing": HIP events round every MLP launch of a NIF render (mi_get_nif_timing)
+  uint32_t nifGenerations = kNifGenerations;   // MI_RAYLIB_NIF_GENERATIONS / "nif_generations": MLP workgroups launched per resident slot (nif_launch_mlp; measurement knob)
+  bool rootStart = true;           // MI_RAYLIB_NO_ROOT_START / "root_start": a cast whose origin lies strictly inside the root's box starts at node 1
+  bool sayGrid = false;            // MI_RAYLIB_SAY_GRID / "say_grid": print every persistent launch's grid to stderr (what the runtime said stays resident)
   // the two options that select ARITHMETIC (every other option leaves every result bit alone):
   bool doubleFallback = false;     // "double_fallback": the reference's ALLOW_DOUBLE_FALLBACK=1 build (CMakeLists.txt:13,34-41; Mesh.cpp:38-51), bit-exact to the oracle in that mode
   bool fast = false;               // "fast": the tolerance tier (FMA box / triangle tests; plain path-trace renders of the default kernel only)
@@ -144,6 +150,16 @@ struct SceneOptions {
       fullStats = b; return true;
     }
 #if MI_RAYLIB_VARIANTS
+    // (the tolerance tier is a build of the default kernel only: while it is set, nothing that selects another kernel is accepted -
+    // the same refusal, whichever of the two options comes first)
+    if (fast && (key == "kernel" || key == "waves" || key == "spec" || key == "merge" || key == "tune")) {
+      SceneOptions probe = *this; probe.fast = false;
+      if (!probe.set(key, v)) { why = probe.why; return false; }
+      if (probe.kernelChoice != 1 || probe.specLeaf || probe.wavesPerSimd != 6 || !probe.mergeTurns || !(probe.tune == kDefaultTune)) {
+        why = "fast is a build of the default kernel only (kernel 1, 6 waves, one SHADE / GEN turn, default weights, no spec): clear fast first"; return false;
+      }
+      return true;      // (a default value: nothing to change)
+    }
     if (key == "kernel") { if (!number(v, 0, 3, q)) return false; kernelChoice = (int)q; return true; }
     if (key == "pool_waves") { if (!number(v, 4, 16, q) || (q != 4 && q != 8 && q != 16)) return false; poolWaves = (int)q; return true; }
     if (key == "pool_tune") {
@@ -172,6 +188,9 @@ struct SceneOptions {
     if (key == "nif_spl") { if (!number(v, 0, 128, q)) return false; nifSamplesPerLaunch = (uint32_t)q; return true; }
     if (key == "pin") return flag01(v, pin);
     if (key == "nif_timing") return flag01(v, nifTiming);
+    if (key == "nif_generations") { if (!number(v, 1, 4096, q)) return false; nifGenerations = (uint32_t)q; return true; }
+    if (key == "root_start") return flag01(v, rootStart);
+    if (key == "say_grid") return flag01(v, sayGrid);
     if (key == "nif_overlap") return flag01(v, nifOverlap);
     if (key == "nif_trace_wgs") { if (!number(v, 0, 16, q)) return false; nifTraceWgs = (uint32_t)q; return true; }
     if (key == "coords") return flag01(v, coords);
@@ -218,12 +237,14 @@ struct SceneOptions {
                                          {"MI_RAYLIB_NIF_SHAPE", "nif_shape"}, {"MI_RAYLIB_TUNE", "tune"},
                                          {"MI_RAYLIB_POOL_TUNE", "pool_tune"}, {"MI_RAYLIB_POOL_WAVES", "pool_waves"}, {"MI_RAYLIB_CUS", "cus"},
                                          {"MI_RAYLIB_NIF_OVERLAP", "nif_overlap"}, {"MI_RAYLIB_COORDS", "coords"},
-                                         {"MI_RAYLIB_NIF_TRACE_WGS", "nif_trace_wgs"}};
+                                         {"MI_RAYLIB_NIF_TRACE_WGS", "nif_trace_wgs"}, {"MI_RAYLIB_NIF_GENERATIONS", "nif_generations"}};
     // (an unparsable environment value is ignored: the option keeps its default. The two options that select ARITHMETIC,
     // double_fallback and fast, are deliberately not in this list: a process that says "bit-exact" must not change tier
     // because of a variable somebody exported)
     for (const auto& m : map) if (const char* e = getenv(m[0])) (void)set(m[1], e);
     if (getenv("MI_RAYLIB_NO_TILES")) tiles = false;
+    if (getenv("MI_RAYLIB_NO_ROOT_START")) rootStart = false;
+    if (getenv("MI_RAYLIB_SAY_GRID")) sayGrid = true;
   }
 };
 
@@ -238,6 +259,7 @@ struct LaunchSlot {
   float* d_segPart = nullptr; size_t segPartFloats = 0;     // [segments][n][3]
   float2* d_coords = nullptr; size_t coordsCap = 0;         // the stream's pixel coordinates, compact (WaveExtras::coords)
   uint32_t* d_poolScratch = nullptr; size_t poolScratchWords = 0;   // kernel 3 (variants build): [PG_WORDS][slots of the grid]
+  hipEvent_t lastWork = nullptr;                              // recorded behind everything the scene enqueued on `stream` (launchRender): what ~mi_scene waits for
 };
 
 struct mi_scene {
@@ -251,6 +273,8 @@ struct mi_scene {
   std::vector<LaunchSlot> slots;
   std::map<const void*, int> residentPerCU;      // workgroups of a kernel that stay resident on one compute unit (hipOccupancyMaxActiveBlocksPerMultiprocessor), asked once per kernel
   uint32_t cus() const { return opt.cus ? opt.cus : (uint32_t)numCUs; }
+  // the scene as one launch sees it: option "root_start" decides whether the walk may start below the root
+  DeviceScene view() const { DeviceScene v = ds; if (!opt.rootStart) v.rootInterior = 0; return v; }
   uint32_t residentBlocks(const void* kern, int threads, size_t ldsBytes) {
     auto it = residentPerCU.find(kern);
     if (it == residentPerCU.end()) {
@@ -285,18 +309,25 @@ struct mi_scene {
   float* d_segTotal = nullptr;                                // sample-at-a-time NIF renders: sum of the finished segments, [n][3]
   uint32_t scratchSamples = 0;                                // samples per launch the slot buffers are sized for
   uint32_t scratchAsked = 0;                                  // the MI_RAYLIB_NIF_SPL value they were sized under (0 = default)
+  bool scratchOneSet = false;                                 // two slot sets did not fit the memory budget: this render runs without the overlap
   std::vector<std::pair<hipEvent_t, hipEvent_t>> nifTimes;    // option "nif_timing": events round the MLP launches since the last mi_get_nif_timing
 
   ~mi_scene() {
     (void)hipSetDevice(device);
-    (void)hipDeviceSynchronize();      // nothing of this scene's may still be in flight (device renders are asynchronous) when its buffers go
+    // Nothing of this scene's may still be in flight when its buffers go: mi_render_device is asynchronous and the caller may
+    // destroy the scene right behind it. The wait is for THIS scene's work only - the event every launchRender records behind
+    // what it enqueued on its stream (work on nifAux is always joined back into that stream before the event) - so destroying a
+    // scene does not wait for other scenes' or replicas' launches on the device. (The events are the scene's own: the caller's
+    // stream may be gone by now. hipFree below synchronises on its own account in this runtime; correctness does not rest on it.)
+    for (LaunchSlot& l : slots) if (l.lastWork) (void)hipEventSynchronize(l.lastWork);
+    if (nifAux) (void)hipStreamSynchronize(nifAux);
     for (void* p : allocations) (void)hipFree(p);
     if (d_rng) (void)hipFree(d_rng);
     freeNifSlots();
     for (NifSlots& q : nifSlots) { if (q.count) (void)hipFree(q.count); if (q.traced) (void)hipEventDestroy(q.traced); if (q.done) (void)hipEventDestroy(q.done); }
     if (nifAux) (void)hipStreamDestroy(nifAux);
     if (d_segTotal) (void)hipFree(d_segTotal);
-    for (LaunchSlot& l : slots) { if (l.d_workCounter) (void)hipFree(l.d_workCounter); if (l.d_segPart) (void)hipFree(l.d_segPart); if (l.d_coords) (void)hipFree(l.d_coords); if (l.d_poolScratch) (void)hipFree(l.d_poolScratch); }
+    for (LaunchSlot& l : slots) { if (l.lastWork) (void)hipEventDestroy(l.lastWork); if (l.d_workCounter) (void)hipFree(l.d_workCounter); if (l.d_segPart) (void)hipFree(l.d_segPart); if (l.d_coords) (void)hipFree(l.d_coords); if (l.d_poolScratch) (void)hipFree(l.d_poolScratch); }
     for (int i = 0; i < 2; ++i) { if (d_batch[i]) (void)hipFree(d_batch[i]); if (pipeStream[i]) (void)hipStreamDestroy(pipeStream[i]); }
     if (nifDone) (void)hipEventDestroy(nifDone);
     for (auto& e : nifTimes) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -319,6 +350,7 @@ LaunchSlot& mi_scene::slotFor(hipStream_t stream) {
   LaunchSlot l;
   l.stream = stream;
   HIP_CHECK(hipMalloc(&l.d_workCounter, sizeof(uint32_t)));
+  if (hipEventCreateWithFlags(&l.lastWork, hipEventDisableTiming) != hipSuccess) { (void)hipFree(l.d_workCounter); throw DeviceError("hipEventCreateWithFlags failed"); }
   slots.push_back(l);
   return slots.back();
 }
@@ -456,7 +488,7 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
     ds.geomFirstVertex = S.keep(upload(geomFirstVertex));
   }
   ds.rootInterior = 0;
-  if (N > 1 && !getenv("MI_RAYLIB_NO_ROOT_START")) {      // (N > 1: the root is an interior node - checked above: a leaf root spans one node)
+  if (N > 1) {      // (N > 1: the root is an interior node - checked above: a leaf root spans one node; option "root_start" = 0 clears the flag per launch)
     ds.rootLoX = nodes[0].minx; ds.rootHiX = nodes[0].maxx; ds.rootLoY = nodes[0].miny; ds.rootHiY = nodes[0].maxy;
     ds.rootLoZ = nodes[0].minz; ds.rootHiZ = nodes[0].maxz; ds.rootInterior = node_is_leaf(nodes[0]) ? 0u : 1u;
   }
@@ -474,10 +506,14 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
   ds.counters = S.d_counters;
 }
 
-// Slots per pixel per launch in NIF renders (44 B each). A launch holds whole segments (ray_math.h segment_samples);
-// more samples per launch mean more (pixel, segment) atoms per lane and fewer launch tails: 128 by default, fewer
-// when n x samples x 44 B would pass 16 GiB (never less than one segment). Option "nif_spl" overrides (1..128,
-// rounded up to whole segments).
+// Slots per pixel per launch in NIF renders: 48 B each (u, v, bgr, colour, throughput, list entry), and TWO sets of them when
+// the render has more than one sample batch and the overlap is on (nif_overlap). A launch holds whole segments (ray_math.h
+// segment_samples); more samples per launch mean more (pixel, segment) atoms per lane and fewer launch tails: 128 by
+// default, fewer when n x samples x 48 B x sets would pass the budget - 32 GiB or half of what the device has free (plus
+// what this scene already holds), whichever is less (the 1440^2 frame at 128 samples and two sets takes 25.5 GB) -, never
+// less than one segment; if two sets of one segment do not fit, the render runs with one (no overlap). Option "nif_spl"
+// overrides the sample count (1..128, rounded up to whole segments). None of this changes a result bit (the accumulate
+// pass replays the reference's order whatever the batching: test_nif_render_sample_batching_is_order_exact).
 // slot-mode (NIF) launches: at most this many workgroups, each wave of which may leave kEnvChunk - 1 padded entries in the escaped-slot list
 constexpr uint32_t kMaxSlotWorkgroups = 4096;
 
@@ -488,14 +524,26 @@ void ensureScratch(mi_scene& S, size_t n) {
     uint32_t v = (asked >= 1 && asked <= 128) ? asked : 128u;
     v = ((v + segLen - 1) / segLen) * segLen;
     v = std::min(v, std::max(segLen, ((S.ds.samplesPerPixel + segLen - 1) / segLen) * segLen));      // no more than the render has
-    if (!(asked >= 1 && asked <= 128))
-      while (v > segLen && (uint64_t)n * v * 44u > ((uint64_t)16 << 30)) v -= segLen;
-    // keep what is there when it still fits this stream and the request has not changed
     const bool haveTwo = S.nifSlots[1].u != nullptr;
+    auto setsFor = [&](uint32_t vv) { return (S.opt.nifOverlap && S.ds.samplesPerPixel > vv) ? 2u : 1u; };
+    constexpr uint64_t kSlotBytes = 48;
+    uint64_t budget = (uint64_t)32 << 30;
+    {
+      size_t freeB = 0, totalB = 0;
+      if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+        const uint64_t held = (uint64_t)S.scratchRays * S.scratchSamples * kSlotBytes * (haveTwo ? 2u : 1u);
+        budget = std::min<uint64_t>(budget, ((uint64_t)freeB + held) / 2);
+      } else (void)hipGetLastError();
+    }
+    if (!(asked >= 1 && asked <= 128))
+      while (v > segLen && (uint64_t)n * v * kSlotBytes * setsFor(v) > budget) v -= segLen;
+    const bool oneSetOnly = setsFor(v) == 2u && (uint64_t)n * v * kSlotBytes * 2u > budget;      // two sets of the smallest launch do not fit
+    // keep what is there when it still fits this stream and the request has not changed
     if (S.scratchRays >= n && S.scratchAsked == asked && S.scratchSamples >= segLen && S.scratchSamples % segLen == 0 &&
-        (haveTwo || !(S.opt.nifOverlap && S.ds.samplesPerPixel > S.scratchSamples))) return;
+        (haveTwo || oneSetOnly || !(S.opt.nifOverlap && S.ds.samplesPerPixel > S.scratchSamples))) return;
     S.scratchAsked = asked;
-    if (v != S.scratchSamples || (!haveTwo && S.opt.nifOverlap && S.ds.samplesPerPixel > v)) { S.scratchSamples = v; S.scratchRays = 0; }     // slot buffers are sized for n x v (x two sets)
+    S.scratchOneSet = oneSetOnly;
+    if (v != S.scratchSamples || (!haveTwo && !oneSetOnly && S.opt.nifOverlap && S.ds.samplesPerPixel > v)) { S.scratchSamples = v; S.scratchRays = 0; }     // slot buffers are sized for n x v (x two sets)
   }
   if (S.scratchRays >= n) return;
   if (S.nifPending) { HIP_CHECK(hipDeviceSynchronize()); S.nifPending = false; }      // an earlier NIF render may still read the old buffers
@@ -507,7 +555,7 @@ void ensureScratch(mi_scene& S, size_t n) {
   HIP_CHECK(hipMalloc(&S.d_rng, n * sizeof(Rng)));
   HIP_CHECK(hipMalloc(&S.d_segTotal, 3 * n * sizeof(float)));
   // the second set only where it is used: renders of more than one sample batch with the overlap on
-  const int sets = (S.opt.nifOverlap && S.ds.samplesPerPixel > S.scratchSamples) ? 2 : 1;
+  const int sets = (S.opt.nifOverlap && S.ds.samplesPerPixel > S.scratchSamples && !S.scratchOneSet) ? 2 : 1;
   for (int k = 0; k < sets; ++k) {
     mi_scene::NifSlots& q = S.nifSlots[k];
     HIP_CHECK(hipMalloc(&q.u, slots * sizeof(float)));
@@ -536,6 +584,7 @@ template <bool STATS>
 void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStream_t stream, const WaveExtras& ex = WaveExtras{}, uint32_t wgCap = 0) {
   LaunchSlot& slot = S.slotFor(stream);
   uint32_t* workCounter = slot.d_workCounter;
+  const DeviceScene dsv = S.view();
   // Streams are walked in 8x8 pixel tiles of window-width rows (a whole window, a batch of it, or one rank's
   // 8-row bands are all sequences of full rows); the walk is only a work ORDER, any stream stays correct.
   const uint32_t w = (uint32_t)S.params.window_w;
@@ -594,11 +643,8 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
       return (uint32_t)wgs;
     };
     auto go = [&](auto kern) {
-#if MI_RAYLIB_VARIANTS
-      static const bool say = getenv("MI_RAYLIB_SAY_GRID") != nullptr;      // (test build: what the runtime said stays resident)
-      if (say) fprintf(stderr, "mi_raylib: grid %u workgroups = %u units x %u resident\n", grid(kern, 256, 0), S.cus(), S.residentBlocks(reinterpret_cast<const void*>(kern), 256, 0));
-#endif
-      hipLaunchKernelGGL(kern, dim3(grid(kern, 256, 0)), dim3(256), 0, stream, S.ds, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
+      if (S.opt.sayGrid) fprintf(stderr, "mi_raylib: grid %u workgroups = %u units x %u resident\n", grid(kern, 256, 0), S.cus(), S.residentBlocks(reinterpret_cast<const void*>(kern), 256, 0));
+      hipLaunchKernelGGL(kern, dim3(grid(kern, 256, 0)), dim3(256), 0, stream, dsv, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
     };
     if (S.opt.doubleFallback) {
       // the ALLOW_DOUBLE_FALLBACK=1 variant: the phase-scheduled kernel's 4-wave build with the binary64 edge functions compiled in
@@ -628,7 +674,7 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
           HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
           S.poolAttrSet[STATS ? 1 : 0][which] = true;
         }
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * W), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, S.opt.poolTune, tileW, exs, slot.d_poolScratch, stride);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * W), ldsBytes, stream, S.view(), d_rays, cnt, workCounter, S.opt.poolTune, tileW, exs, slot.d_poolScratch, stride);
       };
       if (W == 4) goPool(path_trace_pool_kernel<STATS, 4, 400, 4>, 0);
       else if (W == 8) goPool(path_trace_pool_kernel<STATS, 8, 800, 4>, 1);
@@ -643,7 +689,7 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
         S.ldsAttrSet[STATS ? 1 : 0] = true;
       }
       const uint32_t blocks = (uint32_t)std::min<uint64_t>((items + 1023) / 1024, S.cus());
-      hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), ldsBytes, stream, S.ds, d_rays, cnt, workCounter, ldsNodes, S.opt.tune, tileW, exs);
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), ldsBytes, stream, S.view(), d_rays, cnt, workCounter, ldsNodes, S.opt.tune, tileW, exs);
     } else if (S.opt.specLeaf) {
       if (!STATS) go(path_trace_wavefront_kernel<false, false, 256, 5, true>);
       else go(path_trace_wavefront_kernel<STATS, false, 256, 4, true>);
@@ -680,9 +726,9 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
   const dim3 block(256), grid((cnt + 255) / 256);
   if (mode == MI_MODE_SHADOW_TRACE) {
     const f3 light = mk(18.f, 257.f, -1060.f);          // trace.cpp:247, src/IpuScene.cpp:447
-    if (S.opt.doubleFallback) hipLaunchKernelGGL((shadow_trace_kernel<false, true>), grid, block, 0, stream, S.ds, d_rays, cnt, .05f, light);
-    else if (S.opt.fullStats) hipLaunchKernelGGL(shadow_trace_kernel<true>, grid, block, 0, stream, S.ds, d_rays, cnt, .05f, light);
-    else hipLaunchKernelGGL(shadow_trace_kernel<false>, grid, block, 0, stream, S.ds, d_rays, cnt, .05f, light);
+    if (S.opt.doubleFallback) hipLaunchKernelGGL((shadow_trace_kernel<false, true>), grid, block, 0, stream, S.view(), d_rays, cnt, .05f, light);
+    else if (S.opt.fullStats) hipLaunchKernelGGL(shadow_trace_kernel<true>, grid, block, 0, stream, S.view(), d_rays, cnt, .05f, light);
+    else hipLaunchKernelGGL(shadow_trace_kernel<false>, grid, block, 0, stream, S.view(), d_rays, cnt, .05f, light);
   } else if (mode == MI_MODE_PATH_TRACE) {
     // (the ALLOW_DOUBLE_FALLBACK=1 variant is compiled into the phase-scheduled kernel and the shadow kernel: it always takes them)
     // (the phase-scheduled kernel keeps a path's bounce count in 30 bits)
@@ -693,8 +739,8 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
       else launchWavefront<false>(S, d_rays, cnt, stream);
     } else if (!S.nif.loaded()) {
       // sample loop inside the kernel (src/IpuScene.cpp:441: vertexSampleCount = samplesPerPixel)
-      if (S.opt.fullStats) hipLaunchKernelGGL(path_trace_kernel<true>, grid, block, 0, stream, S.ds, d_rays, cnt, 0u, S.ds.samplesPerPixel, (Rng*)nullptr);
-      else hipLaunchKernelGGL(path_trace_kernel<false>, grid, block, 0, stream, S.ds, d_rays, cnt, 0u, S.ds.samplesPerPixel, (Rng*)nullptr);
+      if (S.opt.fullStats) hipLaunchKernelGGL(path_trace_kernel<true>, grid, block, 0, stream, S.view(), d_rays, cnt, 0u, S.ds.samplesPerPixel, (Rng*)nullptr);
+      else hipLaunchKernelGGL(path_trace_kernel<false>, grid, block, 0, stream, S.view(), d_rays, cnt, 0u, S.ds.samplesPerPixel, (Rng*)nullptr);
     } else {
       // Repeat(spp){ trace 1 sample; uv pre-pass; NIF; env post-pass }  (src/IpuScene.cpp:571-583)
       // NIF renders of one scene share its slot scratch: whatever streams they are enqueued on, each waits for the
@@ -718,6 +764,7 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
         if (two && !S.nifAux) HIP_CHECK(hipStreamCreateWithFlags(&S.nifAux, hipStreamNonBlocking));
         hipStream_t mlpStream = two ? S.nifAux : stream;
         uint32_t b = 0;
+        try {
         for (uint32_t s0 = 0; s0 < S.ds.samplesPerPixel; s0 += S.scratchSamples, ++b) {
           mi_scene::NifSlots& q = S.nifSlots[two ? (b & 1u) : 0u];
           const uint32_t sc = std::min<uint32_t>(S.scratchSamples, S.ds.samplesPerPixel - s0);
@@ -733,20 +780,26 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
           if (two) { HIP_CHECK(hipEventRecord(q.traced, stream)); HIP_CHECK(hipStreamWaitEvent(mlpStream, q.traced, 0)); }
           std::pair<hipEvent_t, hipEvent_t> tm{nullptr, nullptr};
           if (S.opt.nifTiming) { HIP_CHECK(hipEventCreate(&tm.first)); HIP_CHECK(hipEventCreate(&tm.second)); S.nifTimes.push_back(tm); HIP_CHECK(hipEventRecord(tm.first, mlpStream)); }
-          nif_launch_mlp(S.nif, q.u, q.v, q.index, q.count, cnt * sc, q.bgr, nullptr, mlpStream, true, S.opt.nifShape, S.cus());
+          nif_launch_mlp(S.nif, q.u, q.v, q.index, q.count, cnt * sc, q.bgr, nullptr, mlpStream, true, S.opt.nifShape, S.cus(), S.opt.nifGenerations);
           if (tm.second) HIP_CHECK(hipEventRecord(tm.second, mlpStream));
           hipLaunchKernelGGL(nif_accumulate_kernel, grid, block, 0, mlpStream, d_rays, cnt, sc, segShift, ex.segBase, q.color, q.tp, q.u, q.bgr);
           if (two) { HIP_CHECK(hipEventRecord(q.done, mlpStream)); q.donePending = true; }
         }
         if (two) for (mi_scene::NifSlots& q : S.nifSlots) if (q.donePending) { HIP_CHECK(hipStreamWaitEvent(stream, q.done, 0)); q.donePending = false; }
+        } catch (...) {
+          // a launch or a HIP call failed with MLP / accumulate passes queued on nifAux: they write the caller's rgb, so the
+          // error must not return while they run behind the caller's stream (mi_render_device) - wait for them here
+          if (two) { (void)hipStreamSynchronize(S.nifAux); for (mi_scene::NifSlots& q : S.nifSlots) q.donePending = false; }
+          throw;
+        }
       } else {
         const uint32_t segLen = segment_samples(S.ds.samplesPerPixel);
         for (uint32_t s = 0; s < S.ds.samplesPerPixel; ++s) {
           // a new segment: the finished ones move to the running total, rgb restarts from zero
           if (s != 0 && s % segLen == 0) hipLaunchKernelGGL(nif_segment_roll_kernel, grid, block, 0, stream, d_rays, S.d_segTotal, cnt, s / segLen, 0u);
-          if (S.opt.fullStats) hipLaunchKernelGGL(path_trace_kernel<true>, grid, block, 0, stream, S.ds, d_rays, cnt, s, 1u, S.d_rng);
-          else hipLaunchKernelGGL(path_trace_kernel<false>, grid, block, 0, stream, S.ds, d_rays, cnt, s, 1u, S.d_rng);
-          nif_env_pass(S.nif, d_rays, cnt, radians, S.nifSlots[0].u, S.nifSlots[0].v, S.nifSlots[0].bgr, S.maxNifBatch, stream, S.opt.nifShape, S.cus());
+          if (S.opt.fullStats) hipLaunchKernelGGL(path_trace_kernel<true>, grid, block, 0, stream, S.view(), d_rays, cnt, s, 1u, S.d_rng);
+          else hipLaunchKernelGGL(path_trace_kernel<false>, grid, block, 0, stream, S.view(), d_rays, cnt, s, 1u, S.d_rng);
+          nif_env_pass(S.nif, d_rays, cnt, radians, S.nifSlots[0].u, S.nifSlots[0].v, S.nifSlots[0].bgr, S.maxNifBatch, stream, S.opt.nifShape, S.cus(), S.opt.nifGenerations);
         }
         if (S.ds.samplesPerPixel > segLen) hipLaunchKernelGGL(nif_segment_roll_kernel, grid, block, 0, stream, d_rays, S.d_segTotal, cnt, 0u, 1u);
       }
@@ -757,6 +810,7 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
     throw ArgError("mi_render: unknown render mode");
   }
   HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipEventRecord(S.slotFor(stream).lastWork, stream));      // (~mi_scene waits for it)
 }
 
 }  // namespace
@@ -990,7 +1044,7 @@ int mi_nif_infer_device(mi_scene* scene, const float* d_u, const float* d_v, flo
   if (!scene->nif.loaded()) { g_err = "mi_nif_infer_device: no NIF model loaded"; return MI_ERR_NO_NIF; }
   return guarded([&] {
     HIP_CHECK(hipSetDevice(scene->device));
-    nif_infer(scene->nif, d_u, d_v, d_bgr, n, scene->maxNifBatch, (hipStream_t)hip_stream, scene->opt.nifShape, scene->cus());
+    nif_infer(scene->nif, d_u, d_v, d_bgr, n, scene->maxNifBatch, (hipStream_t)hip_stream, scene->opt.nifShape, scene->cus(), scene->opt.nifGenerations);
     HIP_CHECK(hipGetLastError());
   });
 }

@@ -10,8 +10,25 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 
+def _install_abort_trace():
+    """tests/native/abort_trace.c: the native backtrace of the thread that calls abort() (or faults), written to a dup of the
+    original stderr. Installed once, before any test; a box without gcc just goes without it."""
+    import ctypes
+    src = ROOT / "tests" / "native" / "abort_trace.c"
+    out = ROOT / "tests" / "native" / "libabort_trace.so"
+    try:
+        if not out.exists() or out.stat().st_mtime < src.stat().st_mtime:
+            subprocess.run(["gcc", "-O1", "-g", "-fPIC", "-shared", "-o", str(out), str(src)], check=True)
+        lib = ctypes.CDLL(str(out))
+        if lib.abort_trace_install(os.dup(2)) != 0:
+            print("[conftest] abort_trace_install failed", file=sys.stderr)
+    except Exception as e:
+        print(f"[conftest] no native abort trace: {e}", file=sys.stderr)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    _install_abort_trace()
 
 
 @pytest.fixture(scope="session", autouse=True)

@@ -976,18 +976,32 @@ def test_launch_grids_follow_the_compute_unit_count(scenes):
             assert_streams_identical(got, want, f"plain render on a grid for {cus} compute units")
         with pytest.raises(irl.RaylibError):
             irl.IpuScene(d).set_option("cus", 5000)
+        # "root_start" (a cast from inside the root's box starts at node 1) is a per-scene option now, not a process-wide
+        # environment read: both settings give the oracle's bytes, and the instrumented build counts the same node visits
+        # either way (the root counts as visited when it is skipped)
+        visits = []
+        for rs in (1, 0):
+            dev = irl.IpuScene(d).set_option("root_start", rs).set_option("full_stats", 1)
+            got = s.init_ray_stream(); dev.run(got, irl.MODE_PATH_TRACE)
+            assert_streams_identical(got, want, f"root_start={rs}")
+            visits.append(dev.counters()["nodes_visited"]); dev.close()
+        assert visits[0] == visits[1] > 0
     sp = scenes["spheres"]
     with _desc_restored(sp.desc) as d:
         rng = np.random.default_rng(6)
         ks, bs, relu = _nif_weights(rng, hidden=64, embed=12, layers=4)
         d.set_image(96, 64); d.samples_per_pixel = 20; d.path_trace = 1
         frames = []
-        for cus in (0, 3):
+        for cus, gens in ((0, None), (3, None), (0, 1), (2, 7)):
             dev = irl.IpuScene(d).set_option("cus", cus)
+            if gens is not None: dev.set_option("nif_generations", gens)      # MLP workgroups per resident slot: per scene, any value covers the same rows
             dev.setNif(ks, bs, relu, 12, 3.43, np.array([-2.35, -2.26, -1.96], np.float32), True)
             got = sp.init_ray_stream(); dev.run(got, irl.MODE_PATH_TRACE); dev.close()
             frames.append(got)
-        assert_streams_identical(frames[1], frames[0], "NIF render on a grid for 3 compute units")
+        for k in (1, 2, 3):
+            assert_streams_identical(frames[k], frames[0], "NIF render on another grid (compute units / MLP generations)")
+        with pytest.raises(irl.RaylibError):
+            irl.IpuScene(d).set_option("nif_generations", 0)
 
 
 def test_work_units_fetch_coordinates_from_the_compact_copy_or_the_records(scenes):
@@ -1410,6 +1424,14 @@ def test_fast_tier_axis_parallel_rays_and_refused_combinations(scenes):
                 fast.set_option(key, 1)
         with pytest.raises(irl.RaylibError, match="cannot be combined"):
             irl.IpuScene(d).set_option("double_fallback", 1).set_option("fast", 1)
+        # the variants build refuses the tier next to another kernel choice WHICHEVER option comes first (it used to accept
+        # waves / merge / spec / kernel / tune behind fast = 1 and then render the tier anyway), and takes the defaults
+        for key, value in (("waves", 5), ("merge", 0), ("spec", 1), ("kernel", 2), ("tune", "8,16,24")):
+            with pytest.raises(irl.RaylibError, match="fast is a build of the default kernel only"):
+                irl.IpuScene(d, variants=True).set_option("fast", 1).set_option(key, value)
+            with pytest.raises(irl.RaylibError, match="fast is a build of the default kernel only"):
+                irl.IpuScene(d, variants=True).set_option(key, value).set_option("fast", 1)
+        irl.IpuScene(d, variants=True).set_option("fast", 1).set_option("waves", 6).set_option("merge", 1).set_option("spec", 0).set_option("kernel", 1).close()
         rng = np.random.default_rng(3)
         ks, bs, relu = _nif_weights(rng, hidden=32, layers=2)
         fast.setNif(ks, bs, relu, 12, 3.43, np.array([-2.35, -2.26, -1.96], np.float32), True)
