@@ -432,6 +432,8 @@ def main():
 
     for _ in range(args.warmup):
         frame()
+    if args.warmup == 0:
+        gather()          # (a collective's first call builds its channels: never inside the timed region, whatever --warmup says)
     barrier()
     dev.reset_counters()
     ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
