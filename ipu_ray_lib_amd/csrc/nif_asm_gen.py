@@ -1,0 +1,290 @@
+#!/usr/bin/env python3
+"""nif_asm_gen.py - generator of K3a's hand-scheduled body (csrc/nif_asm_kernel.hpp includes its output).
+
+K3a is K3r's dataflow (csrc/nif_regs_kernel.hpp: a wave owns 32 rays for the whole network and keeps their activations
+in registers; the packed weight stream goes through a three-slot LDS ring by LDS-DMA once per 256 rays) with every
+instruction of the dense stack placed by hand: one asm statement per workgroup pass holds all the layers. hipcc only
+compiles what surrounds it (Fourier features into registers, decode, stores). Reference mathematics:
+src/neural_networks/NifModel.cpp:300-327 (dense stack, input re-concatenated where the widths ask for it).
+
+What is placed, per wave (8 waves = 2 per SIMD, 256 registers each):
+  * per weight fragment (1 KiB, A operand, read from the ring by ds_read_b128 D fragments ahead): two
+    v_mfma_f32_16x16x32_f16 (the wave's two 16-ray tiles); the read of fragment f + D sits right behind the second MFMA
+    of fragment f, the counted s_waitcnt lgkmcnt(N) in front of the first MFMA of the fragment it retires (the counts come
+    from a replay of the LDS queue in this generator, not from hand);
+  * a pair of output tiles ends in 8 v_cvt_pk_f16_f32 + 8 v_pk_max_f16 (ReLU on the rounded halves) that write the next
+    layer's B operands; they are dealt one per MFMA into the NEXT pair's MFMAs (accumulators are double-buffered), so no
+    epilogue ever stands between two MFMAs of its own wave;
+  * the LDS-DMA pieces of the next chunk (5 per wave and 40-KiB chunk) one at a time at fixed fragment positions of the
+    first half of a chunk, each 4 scalar instructions + the DMA, never in a burst;
+  * ONE s_waitcnt vmcnt(0) + s_barrier per chunk, placed D fragments BEFORE the chunk's first fragment is consumed (where
+    its first read is issued), so the fragment ring never drains at a chunk boundary: at that point the wave's pieces of
+    the chunk were issued at least half a chunk earlier;
+  * nothing else: no address arithmetic in vector registers besides one v_add per chunk, no scratch, no branch.
+
+Register plan (v0 - v216 are named literally and listed as clobbers; operands live above them):
+  v[0:79]    activations, set A: k-step ks, ray tile m at 8 ks + 4 m  (4 registers = 8 halves)
+  v[80:159]  activations, set B (a layer reads one set and writes the other)
+  v[160:191] accumulators, two buffers of [tile of the pair][ray tile][4]
+  v[192:207] fragment ring, D = 4
+  v[208:215] the pair's bias (C operand of its first MFMAs), [tile][4]
+  v216       LDS address of the chunk being read (slot base + 16 lane)
+  s[40:47]   ring bookkeeping (clobbered)
+
+Usage: nif_asm_gen.py OUT.inc [--kinds FPPCPPL] [--relu 1111110] - writes the asm text as C string literals plus
+`#define`s with the clobber list and the network shape the text was generated for."""
+import argparse
+import sys
+
+HT = 10                      # hidden width / 32
+CH = 4 * HT                  # fragments per chunk
+SLOT = CH * 1024
+RING_SLOTS = 3
+D = 4                        # fragment ring depth
+
+SETA, SETB, ACC, RING, BIAS, VADDR = 0, 80, 160, 192, 208, 216
+S_RD, S_WR, S_SRC0, S_SRC1, S_T0, S_T1, S_END, S_T2 = 40, 41, 42, 43, 44, 45, 46, 47
+LAST_VGPR = 216
+
+
+def vr(base, n=4):
+    return f"v[{base}:{base + n - 1}]" if n > 1 else f"v{base}"
+
+
+class Net:
+    def __init__(self, kinds, relu):
+        assert kinds[0] == "F" and kinds[-1] in "LM" and all(k in "PC" for k in kinds[1:-1])      # M = last layer with concat
+        self.kinds, self.relu = kinds, relu
+        self.ks = [2 if k == "F" else HT + 2 if k in "CM" else HT for k in kinds]
+        # the stream exactly as NifRegsDevice::load lays it out (nif_regs_pack.hpp): per hidden layer pair j, k-step ks, tile
+        # 2j then 2j + 1; the final layer its one tile k-step by k-step, zero fragments up to a multiple of 8; chunks of CH
+        self.frags = []          # (layer, j, ks, tt) or None for padding
+        self.chunks = []         # (first fragment, count)
+        self.bias_base = []      # floats
+        nb = 0
+        for l, k in enumerate(kinds):
+            first = len(self.frags)
+            self.bias_base.append(nb)
+            if k in "LM":
+                nb += 16
+                for ks in range(self.ks[l]):
+                    self.frags.append((l, 0, ks, 0))
+            else:
+                nb += 32 * HT
+                for j in range(HT):
+                    for ks in range(self.ks[l]):
+                        self.frags.append((l, j, ks, 0)); self.frags.append((l, j, ks, 1))
+            while (len(self.frags) - first) % 8:
+                self.frags.append(None)
+            n = len(self.frags) - first
+            for at in range(0, n, CH):
+                self.chunks.append((first + at, min(CH, n - at)))
+        self.bias_floats = nb
+
+
+class Emit:
+    def __init__(self):
+        self.items = []          # ("i", text) | ("read", tag, text) | ("wait", tag)
+
+    def i(self, text): self.items.append(("i", text))
+    def read(self, tag, text): self.items.append(("read", tag, text))
+    def wait(self, tag): self.items.append(("wait", tag))
+
+    def render(self):
+        """Replays the LDS queue (ds_read complete in issue order) and turns every wait-for-tag into the count that retires it."""
+        out, q = [], []
+        for it in self.items:
+            if it[0] == "i":
+                out.append(it[1])
+            elif it[0] == "read":
+                q.append(it[1]); out.append(it[2])
+                assert len(q) <= 15, "lgkmcnt holds 4 bits"
+            else:
+                if it[1] in q:
+                    after = len(q) - q.index(it[1]) - 1
+                    out.append(f"s_waitcnt lgkmcnt({after})")
+                    q = q[len(q) - after:] if after else []
+        assert not q, f"reads never waited for: {q}"
+        return out
+
+
+def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4):
+    net = Net(kinds, relu)
+    e = Emit()
+    nchunks = len(net.chunks)
+    # the fragments a wave really consumes, in order, with their chunk and place in it
+    steps = []
+    for c, (first, cnt) in enumerate(net.chunks):
+        for q in range(cnt):
+            f = net.frags[first + q]
+            if f is not None:
+                steps.append(dict(l=f[0], j=f[1], ks=f[2], tt=f[3], c=c, q=q))
+    nsteps = len(steps)
+
+    def in_set(l):       # the set layer l READS (layer 0 reads the features)
+        return SETA if l % 2 == 1 else SETB
+
+    def out_set(l):
+        return SETA if l % 2 == 0 else SETB
+
+    def chunk_entry(c, first_of_pass=False):
+        """In front of the first READ of chunk c: the wave's LDS-DMA pieces of it have landed, every wave says so, nobody reads
+        chunk c - 2's slot any more (chunk c + 1 will be fetched into it)."""
+        e.i(f"; ---- chunk {c}: its pieces have landed; all waves meet")
+        e.i("s_waitcnt vmcnt(0)")
+        e.i("s_barrier")
+        if not first_of_pass:
+            # s40 = slot of chunk c
+            e.i(f"s_add_u32 s{S_T2}, s{S_RD}, {SLOT}")
+            e.i(f"s_cmp_lt_u32 s{S_T2}, s{S_END}")
+            e.i(f"s_cselect_b32 s{S_RD}, s{S_T2}, %[ring0]")
+        # s41 = slot chunk c + 1 goes to (+ the wave's first piece)
+        e.i(f"s_add_u32 s{S_T2}, s{S_RD}, {SLOT}")
+        e.i(f"s_cmp_lt_u32 s{S_T2}, s{S_END}")
+        e.i(f"s_cselect_b32 s{S_WR}, s{S_T2}, %[ring0]")
+        e.i(f"s_add_u32 s{S_WR}, s{S_WR}, %[wavepiece]")
+        e.i(f"v_add_u32 v{VADDR}, s{S_RD}, %[lane16]")
+
+    def dma_piece(c_next, p):
+        first, cnt = net.chunks[c_next % nchunks]
+        if 8 * p >= cnt:
+            return
+        e.i(f"; LDS-DMA: chunk {c_next % nchunks}{' of the next pass' if c_next >= nchunks else ''}, piece wave + {8 * p}")
+        e.i(f"s_add_u32 s{S_T0}, s{S_SRC0}, {(first + 8 * p) * 1024}")
+        e.i(f"s_addc_u32 s{S_T1}, s{S_SRC1}, 0")
+        e.i(f"s_add_u32 m0, s{S_WR}, {8 * p * 1024}")
+        e.i("s_nop 0")
+        e.i(f"global_load_lds_dwordx4 %[lane16], s[{S_T0}:{S_T1}]")
+
+    def ring_read(si):
+        s = steps[si]
+        e.read(("ring", si), f"ds_read_b128 {vr(RING + 4 * (si % D))}, v{VADDR} offset:{s['q'] * 1024}")
+
+    def bias_read(l, j):
+        tiles = (0,) if net.kinds[l] in "LM" else (2 * j, 2 * j + 1)
+        for t, tile in enumerate(tiles):
+            e.read(("bias", l, j, t), f"ds_read_b128 {vr(BIAS + 4 * t)}, %[biasv] offset:{4 * net.bias_base[l] + 64 * tile}")
+
+    def epilogue(l, j, buf):
+        o = out_set(l)
+        ins = []
+        for m in (0, 1):
+            dst = o + 8 * j + 4 * m
+            for t in (0, 1):
+                a = ACC + 16 * buf + 4 * (2 * t + m)
+                ins.append(f"v_cvt_pk_f16_f32 v{dst + 2 * t}, v{a}, v{a + 1}")
+                ins.append(f"v_cvt_pk_f16_f32 v{dst + 2 * t + 1}, v{a + 2}, v{a + 3}")
+            if net.relu[l]:
+                for k in range(4):
+                    ins.append(f"v_pk_max_f16 v{dst + k}, v{dst + k}, 0")
+        return ins
+
+    # ---------------------------------------------------------------- the pass
+    e.i(f"; K3a pass body: layers {kinds}, hidden {32 * HT}, {nsteps} fragments, {nchunks} chunks (generated by nif_asm_gen.py)")
+    e.i(f"s_add_u32 s{S_END}, %[ring0], {RING_SLOTS * SLOT}")
+    e.i(f"s_mov_b32 s{S_RD}, %[rd]")
+    e.i(f"s_add_u32 s{S_SRC0}, %[stream], %[wavepiece]")      # (64-bit operand: its low half; the high half follows)
+    e.i(f"s_addc_u32 s{S_SRC1}, %[streamhi], 0")
+    chunk_entry(0, first_of_pass=True)
+    for si in range(min(D, nsteps)):
+        assert steps[si]["c"] == 0
+        ring_read(si)
+    bias_read(0, 0)
+
+    pending_epi = []            # VALU of the previous pair, dealt one per MFMA slot from slot `epi_start` of the next pair on
+    pair_slot = 0               # MFMAs issued in the current pair
+    buf = 0
+    dma_next = {}               # chunk -> next piece
+    for si, s in enumerate(steps):
+        l, j, ks, tt, c, q = s["l"], s["j"], s["ks"], s["tt"], s["c"], s["q"]
+        kind = net.kinds[l]
+        last = kind in "LM"
+        KS = net.ks[l]
+        if ks == 0 and tt == 0:
+            pair_slot = 0
+        e.wait(("ring", si))
+        if ks == 0:
+            e.wait(("bias", l, j, tt))
+        for m in (0, 1):
+            # B operand: the layer's input k-step, or a feature k-step
+            act_steps = 0 if kind == "F" else HT
+            if ks < act_steps:
+                b = vr(in_set(l) + 8 * ks + 4 * m)
+            else:
+                b = f"%[f{ks - act_steps}{m}]"
+            if last:
+                d_ = f"%[o{m}]"
+            else:
+                d_ = vr(ACC + 16 * buf + 4 * (2 * tt + m))
+            c_ = vr(BIAS + 4 * tt) if ks == 0 else d_
+            e.i(f"v_mfma_f32_16x16x32_f16 {d_}, {vr(RING + 4 * (si % D))}, {b}, {c_}")
+            pair_slot += 1
+            # fillers behind this MFMA
+            if m == 1:
+                nxt = si + D
+                if nxt < nsteps:
+                    if steps[nxt]["c"] != steps[nxt - 1]["c"]:
+                        chunk_entry(steps[nxt]["c"])
+                    ring_read(nxt)
+            if pending_epi and pair_slot > epi_start:
+                # the previous pair's epilogue is dealt over the FIRST HALF of this pair's MFMAs (all of them when the pair is
+                # short): its values are the next layer's operands from that layer's k-step j on, and the final layer reads the
+                # last pair's output in its last two MFMAs
+                total = 2 * KS if last else 4 * KS
+                until = total if total <= 8 else total // 2
+                per = max(1, -(-len(pending_epi) // max(1, until - pair_slot + 1)))
+                for _ in range(min(per, len(pending_epi))):
+                    e.i(pending_epi.pop(0))
+        # the NEXT pair's bias, as soon as this pair's first MFMAs (which take the bias as C) have issued
+        is_pair_first_done = (ks == 0 and (tt == 1 or last))
+        if is_pair_first_done:
+            if not last and j + 1 < HT:
+                bias_read(l, j + 1)
+            elif l + 1 < len(net.kinds) and not last:
+                bias_read(l + 1, 0)
+        # LDS-DMA pieces of the next chunk at fixed places of this chunk
+        cnt_c = net.chunks[c][1]
+        places = dma_at if cnt_c == CH else tuple(range(1, 2 * 5, 2))
+        if q in places:
+            p = places.index(q)
+            dma_piece(c + 1, p)
+        # end of a pair: its epilogue goes into the next pair's slots
+        if not last and ks == KS - 1 and tt == 1:
+            assert not pending_epi, "the previous pair's epilogue did not fit"
+            pending_epi = epilogue(l, j, buf)
+            buf ^= 1
+    assert not pending_epi
+    # the slot of the next pass's chunk 0 (= where this pass's last entry pointed the fetches)
+    e.i(f"s_sub_u32 %[rd], s{S_WR}, %[wavepiece]")
+    e.i("s_nop 15")
+    e.i("s_nop 15")
+    return net, e.render()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("out")
+    ap.add_argument("--kinds", default="FPPCPPL")
+    ap.add_argument("--relu", default="")
+    ap.add_argument("--dma-at", default="1,6,11,16,21")
+    ap.add_argument("--epi-start", type=int, default=4)
+    a = ap.parse_args()
+    relu = [c == "1" for c in (a.relu or "1" * (len(a.kinds) - 1) + "0")]
+    net, lines = generate(a.kinds, relu, tuple(int(x) for x in a.dma_at.split(",")), a.epi_start)
+    with open(a.out, "w") as f:
+        f.write(f"// generated by nif_asm_gen.py --kinds {a.kinds} --relu {''.join('1' if r else '0' for r in relu)}: do not edit\n")
+        f.write(f"#define MI_NIF_ASM_KINDS \"{a.kinds}\"\n#define MI_NIF_ASM_RELU \"{''.join('1' if r else '0' for r in relu)}\"\n")
+        f.write(f"#define MI_NIF_ASM_CHUNKS {len(net.chunks)}\n#define MI_NIF_ASM_BIAS_FLOATS {net.bias_floats}\n")
+        f.write("#define MI_NIF_ASM_CLOBBERS " + ", ".join(f'"v{k}"' for k in range(LAST_VGPR + 1)) + ", " +
+                ", ".join(f'"s{k}"' for k in range(40, 48)) + ', "scc", "memory"\n')
+        f.write("#define MI_NIF_ASM_BODY \\\n")
+        for ln in lines:
+            f.write(f'  "{ln}\\n\\t" \\\n')
+        f.write('  ""\n')
+    n_mfma = sum(1 for ln in lines if ln.startswith("v_mfma"))
+    print(f"{a.out}: {len(lines)} lines, {n_mfma} MFMAs, {sum(1 for ln in lines if ln.startswith('ds_read'))} LDS reads, "
+          f"{sum(1 for ln in lines if ln.startswith('global_load_lds'))} LDS-DMA pieces, {sum(1 for ln in lines if ln == 's_barrier')} barriers", file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()

@@ -96,15 +96,12 @@ struct NifDevice {
   uint32_t* d_index = nullptr;     // compacted ray indices
   size_t indexCap = 0;
   bool ok = false;
-#if MI_RAYLIB_VARIANTS
-  NifRegsDevice regs;              // the same model packed for K3r (nif_regs_kernel.hpp; variants build only); regs.ok only for the shapes that kernel covers
-#endif
+  NifRegsDevice regs;              // the same model packed as a stream of 1-KiB A fragments in consumption order for the register-resident kernels: K3a
+                                   // (nif_asm_kernel.hpp) and, in the variants build, K3r (nif_regs_kernel.hpp); regs.ok only for the shapes they cover
 
   bool loaded() const { return ok; }
   void release() {
-#if MI_RAYLIB_VARIANTS
     regs.release();
-#endif
     if (d_weights) (void)hipFree(d_weights);
     if (d_count) (void)hipFree(d_count);
     if (d_index) (void)hipFree(d_index);
@@ -176,9 +173,7 @@ struct NifDevice {
     if (hipMalloc(&d_weights, packed.size() * sizeof(_Float16)) != hipSuccess) throw std::runtime_error("NIF: hipMalloc failed");
     (void)hipMemcpy(d_weights, packed.data(), packed.size() * sizeof(_Float16), hipMemcpyHostToDevice);
     if (hipMalloc(&d_count, sizeof(uint32_t)) != hipSuccess) throw std::runtime_error("NIF: hipMalloc failed");
-#if MI_RAYLIB_VARIANTS
     (void)regs.load(numLayers, kernels, biases, rows, cols, relu, embedDim, maxValue, mean, logTonemap);
-#endif
     p = P;
     ok = true;
   }
@@ -600,6 +595,11 @@ __global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : 1) nif_ml
 #endif
 }
 
+__device__ __forceinline__ uint32_t nif_uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+
+inline bool nif_asm_covers(const NifRegsDevice& nr);                                                               // nif_asm_kernel.hpp
+inline void nif_asm_launch(const NifRegsDevice& nr, const float* u, const float* v, const uint32_t* idx, const uint32_t* countPtr,
+                           uint32_t numRows, float* bgrOut, mi_trace_result* rays, hipStream_t stream, bool scatter, uint32_t numCUs);
 inline void nif_regs_launch(const NifRegsDevice& nr, const float* u, const float* v, const uint32_t* idx, const uint32_t* countPtr,
                             uint32_t numRows, float* bgrOut, mi_trace_result* rays, hipStream_t stream, bool scatter, uint32_t numCUs, uint32_t variant);      // nif_regs_kernel.hpp
 
@@ -612,8 +612,10 @@ inline void nif_launch_mlp(const NifDevice& nif, const float* u, const float* v,
                            uint32_t numRows, float* bgrOut, mi_trace_result* rays, hipStream_t stream, bool scatter = false, uint32_t shape = 0, uint32_t numCUs = 256,
                            uint32_t generations = kNifGenerations) {
   if (numRows == 0) return;
+  // shape 6 ("a8") = K3a, the hand-scheduled register-resident kernel (nif_asm_kernel.hpp), for the network shape its body was generated for
+  if (shape == 6 && nif_asm_covers(nif.regs)) { nif_asm_launch(nif.regs, u, v, idx, countPtr, numRows, bgrOut, rays, stream, scatter, numCUs); return; }
 #if MI_RAYLIB_VARIANTS
-  if (shape >= 4 && nif.regs.ok) { nif_regs_launch(nif.regs, u, v, idx, countPtr, numRows, bgrOut, rays, stream, scatter, numCUs, shape == 5 ? 0u : 1u); return; }
+  if (shape >= 4 && shape <= 5 && nif.regs.ok) { nif_regs_launch(nif.regs, u, v, idx, countPtr, numRows, bgrOut, rays, stream, scatter, numCUs, shape == 5 ? 0u : 1u); return; }
 #endif
   if (shape >= 3) shape = 0;
   uint32_t maxTiles = 1;

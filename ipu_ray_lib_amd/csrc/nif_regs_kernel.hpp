@@ -76,7 +76,6 @@ struct NifRegsState {
   uint32_t pendSrc, pendDst, pendF, pendN;      // pendSrc: byte offset of the chunk in the stream (the stream is < 4 GiB)
 };
 
-__device__ __forceinline__ uint32_t nif_uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 __device__ __forceinline__ h8 nif_lds_h8(uint32_t addr) {
 #if MI_NIF_REGS_KO & 4
   h8 x; asm volatile("; no read %0, %1" : "=v"(x) : "v"(addr)); return x;

@@ -39,6 +39,7 @@ struct NifRegsDevice {
   NifRegsLayer* d_layers = nullptr;
   NifRegsCold* d_cold = nullptr;
   float* d_bias = nullptr;          // all layers' biases, 16 per output tile (zero padded)
+  std::vector<NifRegsLayer> layersHost;      // the layer table as uploaded (K3a's launch checks the layer sequence against the one its body was generated for)
   bool ok = false;
 
   void release() {
@@ -48,6 +49,7 @@ struct NifRegsDevice {
     if (d_cold) (void)hipFree(d_cold);
     if (d_bias) (void)hipFree(d_bias);
     d_stream = nullptr; d_chunks = nullptr; d_layers = nullptr; d_cold = nullptr; d_bias = nullptr; ok = false;
+    layersHost.clear();
   }
 
   static bool widthSupported(uint32_t hidden) { return hidden == 64 || hidden == 128 || hidden == 256 || hidden == 320; }
@@ -131,6 +133,7 @@ struct NifRegsDevice {
     if (hipMalloc(&d_stream, stream.size() * sizeof(_Float16)) != hipSuccess) throw std::runtime_error("NIF: hipMalloc failed");
     (void)hipMemcpy(d_stream, stream.data(), stream.size() * sizeof(_Float16), hipMemcpyHostToDevice);
     up(d_chunks, chunks); up(d_layers, layers); up(d_bias, bias);
+    layersHost = layers;
     if (hipMalloc(&d_cold, sizeof(NifRegsCold)) != hipSuccess) throw std::runtime_error("NIF: hipMalloc failed");
     (void)hipMemcpy(d_cold, &P, sizeof P, hipMemcpyHostToDevice);
     ok = true;

@@ -29,6 +29,7 @@
 #include "nif_regs_kernel.hpp"      // K3r, the register-resident MLP kernel (round 4: correct, slower than K3; nif_shape r8 / r8s)
 #endif
 #include "nif_kernels.hpp"
+#include "nif_asm_kernel.hpp"      // K3a, the hand-scheduled register-resident MLP kernel (nif_shape a8)
 #include "scene_blob.hpp"
 
 using namespace mi;
@@ -211,7 +212,7 @@ struct SceneOptions {
     }
     if (key == "nif_shape") {
       const std::string s(v);
-      if (s == "w6") nifShape = 0; else if (s == "t6") nifShape = 1; else if (s == "t4") nifShape = 2;
+      if (s == "w6") nifShape = 0; else if (s == "t6") nifShape = 1; else if (s == "t4") nifShape = 2; else if (s == "a8") nifShape = 6;
 #if MI_RAYLIB_VARIANTS
       else if (s == "r8") nifShape = 4; else if (s == "r8s") nifShape = 5;
 #else

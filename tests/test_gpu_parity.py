@@ -456,9 +456,11 @@ def _nif_weights(rng, hidden=320, embed=12, layers=6):
     return ks, bs, relu
 
 
-@pytest.mark.parametrize("shape", ["w6", "t4", "t6", "r8", "r8s"])
+@pytest.mark.parametrize("shape", ["w6", "t4", "t6", "r8", "r8s", "a8", "a8 on 3 compute units"])
 def test_nif_mlp_against_oracle(scenes, shape):
-    """(both MLP kernels: w6 (the default) / t4 / t6 are the workgroup shapes of nif_mlp_kernel; r8 / r8s name K3r, the
+    """(a8 names K3a, the hand-scheduled register-resident kernel of nif_asm_kernel.hpp, in the shipped library; on a grid for 3
+    compute units every workgroup runs fourteen passes, so the weight ring wraps from pass to pass in all three phases)
+    (both MLP kernels: w6 (the default) / t4 / t6 are the workgroup shapes of nif_mlp_kernel; r8 / r8s name K3r, the
     register-resident kernel of nif_regs_kernel.hpp - measured slower, kept selectable - with its waves in lock-step / staggered)
     MFMA MLP vs the oracle's fp16-rounded-inputs / fp32-accumulate restatement. Tolerance: the decoded
     (exp'd) radiance must agree to 2% relative + 1e-3 absolute for 99.9% of samples and 10% for all — fp32
@@ -470,7 +472,9 @@ def test_nif_mlp_against_oracle(scenes, shape):
     mean = np.array([-2.3514461517333984, -2.2660605907440186, -1.9648972749710083], np.float32) - np.float32(1e-8)
     maxv = 3.4299468994140625
     s = scenes["spheres"]
-    dev = irl.IpuScene(s.desc, variants=shape.startswith("r")).set_option("nif_shape", shape)      # (K3r lives in the variants build)
+    dev = irl.IpuScene(s.desc, variants=shape.startswith("r")).set_option("nif_shape", shape.split()[0])      # (K3r lives in the variants build)
+    if shape.endswith("compute units"):
+        dev.set_option("cus", 3)
     dev.setNif(ks, bs, relu, 12, maxv, mean, True)
     n = 10000 + 37                                           # ragged: not a multiple of 64
     u = rng.random(n).astype(np.float32); v = rng.random(n).astype(np.float32)

@@ -1,0 +1,211 @@
+"""Replay of K3a's generated instruction stream (csrc/nif_asm_gen.py; no GPU): every statement of the hand-scheduled dense stack is
+checked against what the dataflow needs, the way tests/test_asm_pipeline_audit.py checks K3's hand-counted waits.
+
+The replay keeps, per register, WHAT it holds (which weight fragment, which bias tile, which activation) and whether the LDS read
+that fills it has been retired by a counted wait, and walks the text:
+  * every v_mfma takes as A the fragment the packed stream (NifRegsDevice::load) has next for it - landed, read from the chunk slot
+    the wave was told to read -, as B the k-step of its layer's input that belongs to it (an activation register written by the
+    epilogue of the right pair of the previous layer, ReLU applied where the layer has one; or the feature operand), as C the
+    landed bias of its tile in its first k-step and its own accumulator afterwards;
+  * no instruction writes a register an outstanding LDS read will fill, and none reads one before the wait that retires it;
+  * an epilogue convert reads an accumulator only once all its MFMAs were issued at least four MFMAs earlier (the wait states an
+    MFMA result needs before a VALU read are far shorter), and before the next pair that uses the buffer writes it;
+  * the first read of a chunk comes behind the wave's s_waitcnt vmcnt(0) + s_barrier for it, every LDS-DMA piece of a chunk is issued
+    behind the entry of the chunk before it (when the slot it lands in - the slot of the chunk two back - is no longer read by
+    anybody) and in front of the chunk's own entry, every wave issues its share of every chunk exactly once;
+  * lgkmcnt never has to hold more than 15."""
+import re
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "ipu_ray_lib_amd" / "csrc"))
+import nif_asm_gen as gen      # noqa: E402
+
+
+def regs_of(tok):
+    m = re.match(r"v\[(\d+):(\d+)\]$", tok)
+    if m:
+        return list(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return [int(m.group(1))] if m else None
+
+
+def replay(kinds, relu, **kw):
+    net, lines = gen.generate(kinds, relu, **kw)
+    HT, D = gen.HT, gen.D
+    # what the stream holds: consumed fragments in order
+    expect = []
+    for c, (first, cnt) in enumerate(net.chunks):
+        for q in range(cnt):
+            f = net.frags[first + q]
+            if f is not None:
+                expect.append((c, q) + f)
+    holds = {}                 # register -> content
+    pending = []               # outstanding LDS reads: (dest registers, content)
+    cur_chunk_read = None      # chunk whose slot v216 points at
+    entered = set()            # chunks whose entry (vmcnt(0) + barrier) this wave has passed
+    dma = {}                   # chunk (absolute, may be nchunks = next pass's 0) -> pieces issued
+    n_mfma = 0
+    acc_state = {}             # accumulator base -> dict(l, j, tt, m, done k-steps, last mfma index)
+    act = {}                   # activation register -> (layer, j, m, idx, relu applied)
+    step_i = 0                 # index into expect (each consumed twice: m = 0, 1)
+    m_next = 0
+    drained = barrier_after_drain = False
+    last_m0 = None
+    nchunks = len(net.chunks)
+
+    def in_flight(regs):
+        return [p for p in pending if set(p[0]) & set(regs)]
+
+    for ln, t in enumerate(lines):
+        if t.startswith("; ---- chunk"):
+            continue
+        if t.startswith(";"):
+            continue
+        op, _, rest = t.partition(" ")
+        args = [a.strip() for a in rest.split(",")] if rest else []
+        if op == "s_waitcnt":
+            m = re.search(r"lgkmcnt\((\d+)\)", t)
+            if m:
+                n = int(m.group(1))
+                assert n <= 15
+                while len(pending) > n:
+                    dest, content = pending.pop(0)
+                    for k, r in enumerate(dest):
+                        holds[r] = content
+            if "vmcnt(0)" in t:
+                drained = True; barrier_after_drain = False
+            continue
+        if op == "s_barrier":
+            assert drained, f"line {ln}: a barrier without the wave's pieces waited for"
+            barrier_after_drain = True
+            continue
+        if op == "v_add_u32" and args[0] == f"v{gen.VADDR}":
+            # the wave turns to the next chunk's slot: behind vmcnt(0) + barrier
+            assert barrier_after_drain, f"line {ln}: chunk entry without wait + barrier"
+            cur_chunk_read = 0 if cur_chunk_read is None else cur_chunk_read + 1
+            entered.add(cur_chunk_read)
+            # every piece of this chunk must have been issued (by this wave) before its entry - except the first chunk of the pass,
+            # which the previous pass (or the kernel's prologue) fetched
+            if cur_chunk_read > 0:
+                want = len([p for p in range(5) if 8 * p < net.chunks[cur_chunk_read][1]])
+                assert dma.get(cur_chunk_read, 0) == want, (cur_chunk_read, dma.get(cur_chunk_read), want)
+            drained = False
+            continue
+        if op == "ds_read_b128":
+            dest = regs_of(args[0])
+            assert not in_flight(dest), f"line {ln}: read into registers with a read in flight"
+            off = int(re.search(r"offset:(\d+)", t).group(1))
+            if args[1].startswith(f"v{gen.VADDR}"):
+                assert cur_chunk_read in entered
+                content = ("frag", cur_chunk_read, off // 1024)
+                assert off // 1024 < net.chunks[cur_chunk_read][1]
+            else:
+                assert args[1].startswith("%[biasv]")
+                content = ("bias", off)
+            pending.append((dest, content))
+            assert len(pending) <= 15
+            continue
+        if op == "s_add_u32" and args[0] == "m0":
+            last_m0 = int(args[2])
+            continue
+        if op == "global_load_lds_dwordx4":
+            # which chunk: from the source offset of the s_add in front of it
+            src = int(re.search(r", (\d+)$", lines[ln - 4]).group(1)) // 1024
+            tgt = [c for c, (first, cnt) in enumerate(net.chunks) if first <= src < first + cnt][0]
+            p = (src - net.chunks[tgt][0]) // 8
+            assert (src - net.chunks[tgt][0]) % 8 == 0 and last_m0 == 8192 * p
+            absolute = tgt if tgt > (cur_chunk_read or 0) else tgt + nchunks
+            assert absolute == cur_chunk_read + 1, f"line {ln}: a piece of chunk {absolute} issued while chunk {cur_chunk_read} is being read"
+            assert dma.get(absolute, 0) == p, "pieces in order, each once"
+            dma[absolute] = p + 1
+            continue
+        if op == "v_mfma_f32_16x16x32_f16":
+            d_, a_, b_, c_ = args
+            c, q, l, j, ks, tt = expect[step_i]
+            m = m_next
+            kind = net.kinds[l]
+            last = kind in "LM"
+            ra = regs_of(a_)
+            assert not in_flight(ra), f"line {ln}: MFMA reads a fragment that has not landed"
+            assert all(holds.get(r) == ("frag", c, q) for r in ra), f"line {ln}: A operand holds {holds.get(ra[0])}, wanted fragment {(c, q)}"
+            act_steps = 0 if kind == "F" else HT
+            if ks < act_steps:
+                rb = regs_of(b_)
+                base = (gen.SETA if l % 2 == 1 else gen.SETB) + 8 * ks + 4 * m
+                assert rb == list(range(base, base + 4)), (ln, b_, base)
+                for k, r in enumerate(rb):
+                    assert act.get(r) == (l - 1, ks, m, k, bool(relu[l - 1])), f"line {ln}: B register v{r} holds {act.get(r)}"
+            else:
+                assert b_ == f"%[f{ks - act_steps}{m}]", (ln, b_)
+            if last:
+                assert d_ == f"%[o{m}]"
+            else:
+                rd_ = regs_of(d_)
+                assert gen.ACC <= rd_[0] < gen.ACC + 32
+            if ks == 0:
+                rc = regs_of(c_)
+                assert not in_flight(rc)
+                tile = 0 if last else 2 * j + tt
+                assert all(holds.get(r) == ("bias", 4 * net.bias_base[l] + 64 * tile) for r in rc), f"line {ln}: C operand {holds.get(rc[0])}"
+                if not last:
+                    st = acc_state.get(rd_[0])
+                    assert st is None or st.get("converted"), f"line {ln}: accumulator rewritten before its epilogue"
+                    acc_state[rd_[0]] = dict(l=l, j=j, tt=tt, m=m, steps=1, last=n_mfma, converted=False)
+            else:
+                assert c_ == d_
+                if not last:
+                    st = acc_state[rd_[0]]
+                    assert (st["l"], st["j"], st["tt"], st["m"]) == (l, j, tt, m) and st["steps"] == ks
+                    st["steps"] += 1; st["last"] = n_mfma
+            n_mfma += 1
+            m_next ^= 1
+            if m_next == 0:
+                step_i += 1
+            continue
+        if op == "v_cvt_pk_f16_f32":
+            dst = regs_of(args[0])[0]; a0 = regs_of(args[1])[0]; a1 = regs_of(args[2])[0]
+            assert a1 == a0 + 1
+            base = gen.ACC + ((a0 - gen.ACC) // 4) * 4
+            st = acc_state[base]
+            assert st["steps"] == net.ks[st["l"]], f"line {ln}: convert of an unfinished accumulator"
+            assert n_mfma - st["last"] > 4, f"line {ln}: convert {n_mfma - st['last']} MFMAs behind the accumulator's last write"
+            half = (a0 - base) // 2
+            want_dst = (gen.SETA if st["l"] % 2 == 0 else gen.SETB) + 8 * st["j"] + 4 * st["m"] + 2 * st["tt"] + half
+            assert dst == want_dst, (ln, dst, want_dst)
+            act[dst] = (st["l"], st["j"], st["m"], 2 * st["tt"] + half, False)
+            st.setdefault("cv", set()).add(half)
+            if len(st["cv"]) == 2:
+                st["converted"] = True
+            continue
+        if op == "v_pk_max_f16":
+            dst = regs_of(args[0])[0]
+            assert regs_of(args[1])[0] == dst and args[2] == "0"
+            l0, j0, m0_, k0, r0 = act[dst]
+            assert relu[l0] and not r0
+            act[dst] = (l0, j0, m0_, k0, True)
+            continue
+        if op in ("s_add_u32", "s_addc_u32", "s_cmp_lt_u32", "s_cselect_b32", "s_mov_b32", "s_sub_u32", "s_nop"):
+            continue
+        raise AssertionError(f"line {ln}: unexpected instruction {t}")
+    assert step_i == len(expect) and not pending
+    assert n_mfma == 2 * len(expect)
+    # the pieces of the next pass's chunk 0 went out in this pass's last chunk
+    assert dma.get(nchunks) == 5
+    return n_mfma, len(lines)
+
+
+@pytest.mark.parametrize("kinds", ["FPPCPPL", "FPL", "FCPM", "FPPPPPPL"])
+def test_generated_body_replays(kinds):
+    relu = [True] * (len(kinds) - 1) + [False]
+    n_mfma, n_lines = replay(kinds, relu)
+    per_tile = {"F": 40, "P": 200, "C": 240, "L": 10, "M": 12}
+    assert n_mfma == 2 * sum(per_tile[k] for k in kinds)
+
+
+def test_generated_body_other_placements_replay():
+    relu = [True, True, False, True, True, True, False]
+    replay("FPPCPPL", relu, dma_at=(2, 5, 9, 14, 20), epi_start=6)
