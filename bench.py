@@ -110,41 +110,6 @@ def nif_weights(rng, hidden=320, embed=12, layers=6):
     return ks, bs, [1] * (len(dims) - 1) + [0], dims
 
 
-class ClockProbe:
-    """The shader clock the chip holds while the launches inside the `with` block run: a one-wave kernel on a stream of its own
-    reads s_memtime (shader cycles) and s_memrealtime (100 MHz) round them (csrc/probe/gather_probe.hip, cp_*; bounded to `max_ms`
-    whatever happens here). `ghz` is None when the probe library is not there. Boxes of the pool differ by 10 % and more in the clock
-    they hold under an MFMA-dense kernel (MI355X_MICROARCH.md, DVFS give-back item 5): with this figure in the record a slow box
-    reads as a slow box, not as a regression."""
-
-    def __init__(self, torch, max_ms=20000.0):
-        self.torch, self.max_ms, self.ghz, self.timed_out, self.h, self.lib = torch, max_ms, None, None, None, None
-
-    def __enter__(self):
-        try:
-            import __graft_entry__ as ge
-            ge.build_probe()
-            self.lib = C.CDLL(str(ROOT / "ipu_ray_lib_amd" / "libmi_gather_probe.so"))
-            self.lib.cp_start.restype = C.c_void_p; self.lib.cp_start.argtypes = [C.c_double]
-            self.lib.cp_mark.argtypes = [C.c_void_p, C.c_uint32]
-            self.lib.cp_finish.restype = C.c_double; self.lib.cp_finish.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
-            self.h = self.lib.cp_start(self.max_ms)
-            time.sleep(0.005)                      # the probe's wave is resident before the measured launches start
-            self.lib.cp_mark(self.h, 1)
-        except Exception as e:                     # measurement tooling only: never fails the bench
-            self.h = None; self.error = f"{type(e).__name__}: {e}"
-        return self
-
-    def __exit__(self, *exc):
-        if self.h:
-            self.torch.cuda.current_stream().synchronize()
-            to = C.c_int(0)
-            g = self.lib.cp_finish(self.h, C.byref(to))
-            self.ghz = g if g > 0 else None
-            self.timed_out = bool(to.value)
-        return False
-
-
 MEAN_NIF = np.array([-2.3514461517333984, -2.2660605907440186, -1.9648972749710083], np.float32) - np.float32(1e-8)     # nif_metadata.txt: mean - eps
 MAX_NIF = 3.4299468994140625
 
@@ -184,18 +149,17 @@ def config5_record(torch, irl, stream, cores, spp=256, check=True):
     dev.reset_counters(); dev.nif_timing()
     rays = to_device(torch, irl, host)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    with ClockProbe(torch) as cp:
-        e0.record(stream)
-        dev.run_device(rays.data_ptr(), n, irl.MODE_PATH_TRACE, stream.cuda_stream)
-        e1.record(stream)
-        torch.cuda.synchronize()
+    e0.record(stream)
+    dev.run_device(rays.data_ptr(), n, irl.MODE_PATH_TRACE, stream.cuda_stream)
+    e1.record(stream)
+    torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
     c = dev.counters(); tm = dev.nif_timing()
     out = {"workload": f"built-in scene 'monkey' + NIF environment (synthetic 6 x 320 weights), 1440x1440 x {spp} spp (BASELINE config 5 at {spp} of its 4000 samples), one GPU",
            "ms_per_frame": ms, "ms_per_sample": ms / spp, "extrapolated_ms_4000spp": ms / spp * 4000.0,
            "mlp_share": tm["mlp_ms"] / ms, "mlp_ms_per_frame": tm["mlp_ms"], "mlp_launches": tm["launches"],
            "paths_per_s": c["paths"] / (ms * 1e-3), "casts_per_path": c["casts"] / max(c["paths"], 1),
-           "shader_clock_ghz": cp.ghz, "mlp_flops_per_ray": 2 * sum(k * q for k, q in dims)}
+           "mlp_shader_clock_ghz": dev.nif_clock_ghz(), "mlp_flops_per_ray": 2 * sum(k * q for k, q in dims)}
     if check:
         import oracle_lib as ol
         idx = np.arange(0, n, 4099)
@@ -612,19 +576,21 @@ def main():
         ns.setNif(ks, bs, relu, 12, 3.43, np.array([-2.35, -2.27, -1.96], np.float32), True)
         nr = 1440 * 1440
         u = torch.rand(nr, device="cuda"); v = torch.rand(nr, device="cuda"); bgr = torch.empty(nr, 3, device="cuda")
-        ms = time_launches(torch, lambda: ns.nif_infer_device(u.data_ptr(), v.data_ptr(), bgr.data_ptr(), nr, stream.cuda_stream), 5, stream)
-        # the same launches once more beside the clock probe (20 of them: ~40 ms, long enough for the chip to settle at the clock
-        # it holds under this kernel); the timing above stays the un-probed one
-        with ClockProbe(torch) as cp:
-            for _ in range(20):
-                ns.nif_infer_device(u.data_ptr(), v.data_ptr(), bgr.data_ptr(), nr, stream.cuda_stream)
-            torch.cuda.synchronize()
+        # the default kernel for this network (nif_shape auto: K3a, the hand-scheduled register-resident kernel) - 20 launches, the
+        # clock of the last one from the kernel's own counter reads (mi_get_nif_clock) - and nif_mlp_kernel (w6) beside it
+        ms = time_launches(torch, lambda: ns.nif_infer_device(u.data_ptr(), v.data_ptr(), bgr.data_ptr(), nr, stream.cuda_stream), 20, stream)
+        ghz = ns.nif_clock_ghz()
+        ns.set_option("nif_shape", "w6")
+        ms_w6 = time_launches(torch, lambda: ns.nif_infer_device(u.data_ptr(), v.data_ptr(), bgr.data_ptr(), nr, stream.cuda_stream), 20, stream)
+        ns.set_option("nif_shape", "auto")
         flops_per_ray = 2 * sum(k * c for k, c in dims)
         tf = nr * flops_per_ray / (ms * 1e-3) / 1e12
         mfma_cycles = nr / 16.0 * (flops_per_ray / 2.0 / (16 * 32)) * 16.0 / (4 * cus)         # 16 cycles per v_mfma_f32_16x16x32_f16 per SIMD (real MACs only)
-        out["nif"] = {"kernel": "nif_mlp_kernel", "rays": nr, "avg_launch_ms": ms, "rays_per_s": nr / (ms * 1e-3), "flops_per_ray": flops_per_ray,
-                      "shader_clock_ghz": cp.ghz, "shader_clock_note": "delta s_memtime / delta s_memrealtime x 100 MHz in a one-wave probe kernel beside 20 launches (csrc/probe/gather_probe.hip cp_*)",
-                      "matrix_pipe_busy_at_that_clock": (mfma_cycles / (ms * 1e-3 * cp.ghz * 1e9)) if cp.ghz else None,
+        out["nif"] = {"kernel": "nif_asm_kernel (K3a)" if ghz else "nif_mlp_kernel (w6)", "rays": nr, "avg_launch_ms": ms, "rays_per_s": nr / (ms * 1e-3), "flops_per_ray": flops_per_ray,
+                      "shader_clock_ghz": ghz, "shader_clock_note": "delta s_memtime / delta s_memrealtime x 100 MHz of the kernel's first wave, which lives as long as the launch (mi_get_nif_clock): "
+                                                                      "the clock the chip's power management left this launch; boxes of the pool differ",
+                      "matrix_pipe_busy_at_that_clock": (mfma_cycles / (ms * 1e-3 * ghz * 1e9)) if ghz else None,
+                      "nif_mlp_kernel_w6_ms": ms_w6,
                       "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F16_PEAK_TFLOPS,
                                    "dtype": "f16 in / f32 accumulate"}}
         ns.close(); del u, v, bgr
@@ -645,14 +611,6 @@ def main():
         out["fast_tier"] = {"ms_per_frame": ms, "rays_per_s": fcnt["casts"] / 3.0 / (ms * 1e-3), "workload": f"{width}x{height} x {args.spp} spp",
                             "note": "not bit-exact: results within the tolerance stated in tests/test_gpu_parity.py::test_fast_tier_within_its_stated_tolerance"}
         fd.close(); del f_rays
-        # ---------------- K1w's clock: two more launches of the headline frame beside the probe (outside the timed region) ----------------
-        c_rays = to_device(torch, irl, host_rays)      # (a stream of its own: the timed stream keeps exactly the frames the parity check replays)
-        with ClockProbe(torch) as cp:
-            for _ in range(2):
-                dev.run_device(c_rays.data_ptr(), n, irl.MODE_PATH_TRACE, stream.cuda_stream)
-            torch.cuda.synchronize()
-        del c_rays
-        out["roofline"]["shader_clock_ghz"] = cp.ghz
         # ---------------- BASELINE configs 3 and 5 at a fraction of their samples (rates as trace.cpp:328-333 defines them) ----------------
         try:
             ncores = max(1, min(len(os.sched_getaffinity(0)), 16))

@@ -182,6 +182,12 @@ int mi_get_pool_stats(mi_scene* scene, uint64_t stats[8]);
  * of launches. Synchronises the device and clears the record. tools/bench_config5.py reports the MLP's share of a frame
  * from it. No reference counterpart. */
 int mi_get_nif_timing(mi_scene* scene, double out[2]);
+/* The shader clock the last launch of the register-resident MLP kernel (K3a, csrc/nif_asm_kernel.hpp) ran at: out[0] = shader
+ * cycles (s_memtime), out[1] = ticks of the constant 100-MHz counter (s_memrealtime) that the first wave of its first workgroup -
+ * which lives as long as the launch - spent in the kernel; clock in GHz = out[0] / out[1] / 10. Both 0 when the scene's network
+ * runs nif_mlp_kernel (no such record). Synchronises the device. An MFMA-dense kernel runs at the clock the chip's power
+ * management leaves it, which differs from box to box: bench.py quotes this beside the kernel's time. No reference counterpart. */
+int mi_get_nif_clock(mi_scene* scene, uint64_t out[2]);
 
 /* Replaces: IpuScene::loadNifModel (src/IpuScene.cpp:174-187) with the weights handed over as
  * arrays (the file side — nif_metadata.txt + Keras-H5 — is mi_host_nif_load in mi_scene_host.h).
@@ -224,8 +230,13 @@ int mi_scene_set_ray_batch(mi_scene* scene, size_t rays_per_batch);
  *   "tiles"         0 | 1           walk row-structured streams in 8x8 pixel tiles
  *   "seg_budget_kb" N >= 1          partial-sum buffer budget per launch
  *   "nif_spl"       0..128          NIF samples per launch (0 = default)
- *   "nif_shape"     w6 | t6 | t4    workgroup shape of the NIF MLP kernel (w6 = default); the variants build also takes r8 | r8s = the
- *                                   register-resident kernel of csrc/nif_regs_kernel.hpp (measured slower; refused by the shipped library)
+ *   "nif_shape"     auto | a8 | w6 | t6 | t4    which NIF MLP kernel runs: auto (default) = a8 where its generated body covers the network
+ *                                   (the reference's 6 x 320 shape), w6 otherwise; a8 = K3a, the hand-scheduled register-resident kernel
+ *                                   (csrc/nif_asm_kernel.hpp); w6 | t6 | t4 = workgroup shapes of nif_mlp_kernel; the variants build also takes
+ *                                   r8 | r8s = K3r (csrc/nif_regs_kernel.hpp: measured slower; refused by the shipped library)
+ *   "nif_generations" 1..4096       nif_mlp_kernel: workgroups launched per resident slot (measurement knob; default 64)
+ *   "root_start"    0 | 1           a cast whose origin lies strictly inside the root's box starts at node 1 (default 1; exact either way)
+ *   "say_grid"      0 | 1           print every persistent launch's grid to stderr
  *   "pin"           0 | 1           page-lock the caller's stream for the duration of mi_render
  *   "nif_overlap"   0 | 1           NIF renders trace sample batch b + 1 beside the MLP of batch b (two slot sets, a second stream; default 1)
  *   "nif_trace_wgs" 0..16           with nif_overlap: workgroups per compute unit of a trace launch that runs beside the previous batch's MLP

@@ -210,6 +210,7 @@ def device_lib(variants: bool = False) -> C.CDLL:
         lib.mi_get_pool_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         lib.mi_scene_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         lib.mi_get_nif_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        lib.mi_get_nif_clock.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         _device[variants] = lib
     return _device[variants]
 
@@ -484,6 +485,12 @@ class IpuScene:
         c = (C.c_double * 2)()
         self._check(self._lib.mi_get_nif_timing(self._h, c))
         return {"mlp_ms": float(c[0]), "launches": int(c[1])}
+
+    def nif_clock_ghz(self):
+        """The shader clock the last K3a launch ran at (mi_get_nif_clock), None when the network runs nif_mlp_kernel."""
+        c = (C.c_uint64 * 2)()
+        self._check(self._lib.mi_get_nif_clock(self._h, c))
+        return (c[0] / c[1] * 0.1) if c[1] else None
 
     def reset_counters(self):
         self._check(self._lib.mi_reset_counters(self._h))

@@ -40,11 +40,19 @@ HT = 10                      # hidden width / 32
 CH = 4 * HT                  # fragments per chunk
 SLOT = CH * 1024
 RING_SLOTS = 3
-D = 4                        # fragment ring depth
+D = 4                        # fragment ring depth (set_ring_depth)
 
-SETA, SETB, ACC, RING, BIAS, VADDR = 0, 80, 160, 192, 208, 216
+SETA, SETB, ACC, RING = 0, 80, 160, 192
+BIAS, VADDR, LAST_VGPR = RING + 4 * D, RING + 4 * D + 8, RING + 4 * D + 8
 S_RD, S_WR, S_SRC0, S_SRC1, S_T0, S_T1, S_END, S_T2 = 40, 41, 42, 43, 44, 45, 46, 47
-LAST_VGPR = 216
+
+
+def set_ring_depth(d):
+    """(experiments: tools/k3a_lab.py) the registers behind the fragment ring move with its depth"""
+    global D, BIAS, VADDR, LAST_VGPR
+    D = d
+    BIAS, VADDR, LAST_VGPR = RING + 4 * D, RING + 4 * D + 8, RING + 4 * D + 8
+    assert LAST_VGPR <= 224, "the statement's operands need the registers above"
 
 
 def vr(base, n=4):
@@ -104,11 +112,14 @@ class Emit:
                     after = len(q) - q.index(it[1]) - 1
                     out.append(f"s_waitcnt lgkmcnt({after})")
                     q = q[len(q) - after:] if after else []
-        assert not q, f"reads never waited for: {q}"
+        if q:
+            out.append("s_waitcnt lgkmcnt(0)")      # (only the timing-only builds that drop waits leave anything here)
         return out
 
 
-def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4):
+def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4, ko=0, prio=0):
+    """ko (timing-only builds, results wrong; tools/k3a_lab.py): bit 0 no LDS-DMA, bit 1 no barrier, bit 2 no epilogue, bit 3 no
+    fragment reads, bit 4 no waits for fragment reads, bit 5 every second fragment read only. prio: s_setprio for the whole statement."""
     net = Net(kinds, relu)
     e = Emit()
     nchunks = len(net.chunks)
@@ -132,7 +143,8 @@ def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4):
         chunk c - 2's slot any more (chunk c + 1 will be fetched into it)."""
         e.i(f"; ---- chunk {c}: its pieces have landed; all waves meet")
         e.i("s_waitcnt vmcnt(0)")
-        e.i("s_barrier")
+        if not ko & 2:
+            e.i("s_barrier")
         if not first_of_pass:
             # s40 = slot of chunk c
             e.i(f"s_add_u32 s{S_T2}, s{S_RD}, {SLOT}")
@@ -147,7 +159,7 @@ def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4):
 
     def dma_piece(c_next, p):
         first, cnt = net.chunks[c_next % nchunks]
-        if 8 * p >= cnt:
+        if 8 * p >= cnt or ko & 1:
             return
         e.i(f"; LDS-DMA: chunk {c_next % nchunks}{' of the next pass' if c_next >= nchunks else ''}, piece wave + {8 * p}")
         e.i(f"s_add_u32 s{S_T0}, s{S_SRC0}, {(first + 8 * p) * 1024}")
@@ -158,6 +170,11 @@ def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4):
 
     def ring_read(si):
         s = steps[si]
+        if ko & 8 or (ko & 32 and si % 2 == 1):
+            return
+        if ko & 16:
+            e.i(f"ds_read_b128 {vr(RING + 4 * (si % D))}, v{VADDR} offset:{s['q'] * 1024}")
+            return
         e.read(("ring", si), f"ds_read_b128 {vr(RING + 4 * (si % D))}, v{VADDR} offset:{s['q'] * 1024}")
 
     def bias_read(l, j):
@@ -183,6 +200,8 @@ def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4):
     e.i(f"; K3a pass body: layers {kinds}, hidden {32 * HT}, {nsteps} fragments, {nchunks} chunks (generated by nif_asm_gen.py)")
     e.i(f"s_add_u32 s{S_END}, %[ring0], {RING_SLOTS * SLOT}")
     e.i(f"s_mov_b32 s{S_RD}, %[rd]")
+    if prio:
+        e.i(f"s_setprio {prio}")
     e.i(f"s_add_u32 s{S_SRC0}, %[stream], %[wavepiece]")      # (64-bit operand: its low half; the high half follows)
     e.i(f"s_addc_u32 s{S_SRC1}, %[streamhi], 0")
     chunk_entry(0, first_of_pass=True)
@@ -202,7 +221,8 @@ def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4):
         KS = net.ks[l]
         if ks == 0 and tt == 0:
             pair_slot = 0
-        e.wait(("ring", si))
+        if not ko & 16:
+            e.wait(("ring", si))
         if ks == 0:
             e.wait(("bias", l, j, tt))
         for m in (0, 1):
@@ -251,10 +271,12 @@ def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4):
         # end of a pair: its epilogue goes into the next pair's slots
         if not last and ks == KS - 1 and tt == 1:
             assert not pending_epi, "the previous pair's epilogue did not fit"
-            pending_epi = epilogue(l, j, buf)
+            pending_epi = [] if ko & 4 else epilogue(l, j, buf)
             buf ^= 1
     assert not pending_epi
     # the slot of the next pass's chunk 0 (= where this pass's last entry pointed the fetches)
+    if prio:
+        e.i("s_setprio 0")
     e.i(f"s_sub_u32 %[rd], s{S_WR}, %[wavepiece]")
     e.i("s_nop 15")
     e.i("s_nop 15")
@@ -268,9 +290,13 @@ def main():
     ap.add_argument("--relu", default="")
     ap.add_argument("--dma-at", default="1,6,11,16,21")
     ap.add_argument("--epi-start", type=int, default=4)
+    ap.add_argument("--ko", type=int, default=0, help="timing-only knock-outs (results wrong): 1 no LDS-DMA, 2 no barrier, 4 no epilogue, 8 no fragment reads")
+    ap.add_argument("--prio", type=int, default=0)
+    ap.add_argument("--ring", type=int, default=4, help="fragment ring depth")
     a = ap.parse_args()
+    set_ring_depth(a.ring)
     relu = [c == "1" for c in (a.relu or "1" * (len(a.kinds) - 1) + "0")]
-    net, lines = generate(a.kinds, relu, tuple(int(x) for x in a.dma_at.split(",")), a.epi_start)
+    net, lines = generate(a.kinds, relu, tuple(int(x) for x in a.dma_at.split(",")), a.epi_start, a.ko, a.prio)
     with open(a.out, "w") as f:
         f.write(f"// generated by nif_asm_gen.py --kinds {a.kinds} --relu {''.join('1' if r else '0' for r in relu)}: do not edit\n")
         f.write(f"#define MI_NIF_ASM_KINDS \"{a.kinds}\"\n#define MI_NIF_ASM_RELU \"{''.join('1' if r else '0' for r in relu)}\"\n")

@@ -94,6 +94,7 @@ struct NifDevice {
   h8* d_weights = nullptr;
   uint32_t* d_count = nullptr;     // compaction counter
   uint32_t* d_index = nullptr;     // compacted ray indices
+  unsigned long long* d_clock = nullptr;      // K3a: {shader cycles, 100-MHz ticks} one wave spent in the last launch (mi_get_nif_clock)
   size_t indexCap = 0;
   bool ok = false;
   NifRegsDevice regs;              // the same model packed as a stream of 1-KiB A fragments in consumption order for the register-resident kernels: K3a
@@ -105,7 +106,8 @@ struct NifDevice {
     if (d_weights) (void)hipFree(d_weights);
     if (d_count) (void)hipFree(d_count);
     if (d_index) (void)hipFree(d_index);
-    d_weights = nullptr; d_count = nullptr; d_index = nullptr; indexCap = 0; ok = false;
+    if (d_clock) (void)hipFree(d_clock);
+    d_weights = nullptr; d_count = nullptr; d_index = nullptr; d_clock = nullptr; indexCap = 0; ok = false;
   }
 
   // Packs W (Keras [rows=K][cols=N], y = x·W) into A-fragment order of v_mfma_f32_16x16x32_f16 for the
@@ -173,6 +175,8 @@ struct NifDevice {
     if (hipMalloc(&d_weights, packed.size() * sizeof(_Float16)) != hipSuccess) throw std::runtime_error("NIF: hipMalloc failed");
     (void)hipMemcpy(d_weights, packed.data(), packed.size() * sizeof(_Float16), hipMemcpyHostToDevice);
     if (hipMalloc(&d_count, sizeof(uint32_t)) != hipSuccess) throw std::runtime_error("NIF: hipMalloc failed");
+    if (hipMalloc(&d_clock, 2 * sizeof(unsigned long long)) != hipSuccess) throw std::runtime_error("NIF: hipMalloc failed");
+    (void)hipMemset(d_clock, 0, 2 * sizeof(unsigned long long));
     (void)regs.load(numLayers, kernels, biases, rows, cols, relu, embedDim, maxValue, mean, logTonemap);
     p = P;
     ok = true;
@@ -599,7 +603,7 @@ __device__ __forceinline__ uint32_t nif_uniform(uint32_t x) { return (uint32_t)_
 
 inline bool nif_asm_covers(const NifRegsDevice& nr);                                                               // nif_asm_kernel.hpp
 inline void nif_asm_launch(const NifRegsDevice& nr, const float* u, const float* v, const uint32_t* idx, const uint32_t* countPtr,
-                           uint32_t numRows, float* bgrOut, mi_trace_result* rays, hipStream_t stream, bool scatter, uint32_t numCUs);
+                           uint32_t numRows, float* bgrOut, mi_trace_result* rays, hipStream_t stream, bool scatter, uint32_t numCUs, unsigned long long* clockOut);
 inline void nif_regs_launch(const NifRegsDevice& nr, const float* u, const float* v, const uint32_t* idx, const uint32_t* countPtr,
                             uint32_t numRows, float* bgrOut, mi_trace_result* rays, hipStream_t stream, bool scatter, uint32_t numCUs, uint32_t variant);      // nif_regs_kernel.hpp
 
@@ -612,8 +616,10 @@ inline void nif_launch_mlp(const NifDevice& nif, const float* u, const float* v,
                            uint32_t numRows, float* bgrOut, mi_trace_result* rays, hipStream_t stream, bool scatter = false, uint32_t shape = 0, uint32_t numCUs = 256,
                            uint32_t generations = kNifGenerations) {
   if (numRows == 0) return;
-  // shape 6 ("a8") = K3a, the hand-scheduled register-resident kernel (nif_asm_kernel.hpp), for the network shape its body was generated for
-  if (shape == 6 && nif_asm_covers(nif.regs)) { nif_asm_launch(nif.regs, u, v, idx, countPtr, numRows, bgrOut, rays, stream, scatter, numCUs); return; }
+  // shape 7 ("auto", the default) = K3a, the hand-scheduled register-resident kernel (nif_asm_kernel.hpp), for the network shape its
+  // body was generated for (the reference's 6 x 320 with the features re-concatenated in the middle), nif_mlp_kernel's w6 for every
+  // other network; 6 ("a8") asks for K3a by name (and still falls back when the network is not covered)
+  if ((shape == 6 || shape == 7) && nif_asm_covers(nif.regs)) { nif_asm_launch(nif.regs, u, v, idx, countPtr, numRows, bgrOut, rays, stream, scatter, numCUs, nif.d_clock); return; }
 #if MI_RAYLIB_VARIANTS
   if (shape >= 4 && shape <= 5 && nif.regs.ok) { nif_regs_launch(nif.regs, u, v, idx, countPtr, numRows, bgrOut, rays, stream, scatter, numCUs, shape == 5 ? 0u : 1u); return; }
 #endif

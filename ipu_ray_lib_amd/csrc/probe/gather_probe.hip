@@ -117,61 +117,3 @@ extern "C" double gp_run(const void* nodes, uint32_t numNodes, int path, int wal
   }
   return ms;
 }
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// Clock probe: the shader clock the chip holds WHILE another launch runs (MI355X_MICROARCH.md, DVFS give-back item 6: in-kernel
-// clock = delta s_memtime / delta s_memrealtime x 100 MHz). One wave of one workgroup, launched on a stream of its own just before
-// the launch to be measured, reads both counters, sleeps, reads again - until the host sets the stop word (pinned host memory) or
-// `maxRealTicks` of the constant 100-MHz counter have passed (the exit every wave reaches: the probe can never outlive its bound).
-// It occupies one wave slot of one CU and issues a handful of scalar instructions per microsecond: it does not disturb what it
-// measures. Box-to-box spread of a power-limited kernel shows in this number (bench.py: `nif.shader_clock_ghz`).
-namespace {
-__global__ void __launch_bounds__(64) clock_probe_kernel(volatile const uint32_t* stop, unsigned long long* out, unsigned long long maxRealTicks) {
-  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-  unsigned long long c1 = c0, r1 = r0, cb = 0, rb = 0;
-  bool begun = false;
-  for (;;) {
-    __builtin_amdgcn_s_sleep(127);
-    c1 = __builtin_amdgcn_s_memtime(); r1 = __builtin_amdgcn_s_memrealtime();
-    const uint32_t s = *stop;                  // 0 = wait, 1 = the measured launch is running (start counting), 2 = stop
-    if (s == 1u && !begun) { begun = true; cb = c1; rb = r1; }
-    if (s >= 2u || r1 - r0 >= maxRealTicks) break;
-  }
-  if (threadIdx.x == 0) { out[0] = begun ? c1 - cb : c1 - c0; out[1] = begun ? r1 - rb : r1 - r0; out[2] = (r1 - r0 >= maxRealTicks) ? 1ull : 0ull; }
-}
-struct ClockProbe {
-  hipStream_t stream = nullptr;
-  uint32_t* stop = nullptr;                    // pinned host memory, device-visible
-  unsigned long long* out = nullptr;           // pinned host memory
-};
-}  // namespace
-
-// Starts the probe (returns an opaque handle, null on error); maxMs bounds its life whatever the host does afterwards.
-extern "C" void* cp_start(double maxMs) {
-  ClockProbe* p = new ClockProbe;
-  if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipHostMalloc((void**)&p->stop, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
-      hipHostMalloc((void**)&p->out, 3 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) {
-    if (p->stop) (void)hipHostFree(p->stop);
-    if (p->stream) (void)hipStreamDestroy(p->stream);
-    delete p; return nullptr;
-  }
-  *p->stop = 0u; p->out[0] = p->out[1] = p->out[2] = 0ull;
-  const unsigned long long ticks = (unsigned long long)(maxMs * 1e5);      // 100 MHz
-  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, p->stream, p->stop, p->out, ticks);
-  return p;
-}
-// 1 = the interval to be measured begins now, 2 = it ends (the probe exits)
-extern "C" void cp_mark(void* h, uint32_t what) { if (h) { __atomic_store_n(((ClockProbe*)h)->stop, what, __ATOMIC_RELEASE); } }
-// Waits for the probe, returns the clock in GHz over the marked interval (<= 0 on error); *timedOut = 1 when the probe left at its bound.
-extern "C" double cp_finish(void* h, int* timedOut) {
-  if (!h) return -1.0;
-  ClockProbe* p = (ClockProbe*)h;
-  cp_mark(h, 2u);
-  double ghz = -1.0;
-  if (hipStreamSynchronize(p->stream) == hipSuccess && p->out[1] > 0) ghz = (double)p->out[0] / (double)p->out[1] * 0.1;
-  if (timedOut) *timedOut = (int)p->out[2];
-  (void)hipHostFree(p->stop); (void)hipHostFree(p->out); (void)hipStreamDestroy(p->stream);
-  delete p;
-  return ghz;
-}

@@ -109,7 +109,8 @@ struct SceneOptions {
   size_t segBudgetKb = (size_t)8 * 1024 * 1024;   // MI_RAYLIB_SEG_BUDGET_KB / "seg_budget_kb": partial-sum buffer budget per launch
   uint32_t nifSamplesPerLaunch = 0;               // MI_RAYLIB_NIF_SPL / "nif_spl": 0 = default (128, memory permitting)
   bool pin = true;                 // MI_RAYLIB_PIN / "pin": page-lock the caller's stream for the duration of mi_render
-  uint32_t nifShape = 0;           // MI_RAYLIB_NIF_SHAPE / "nif_shape": 0 = w6 (default), 1 = t6, 2 = t4; 4 = r8, 5 = r8s (K3r, nif_regs_kernel.hpp: measured slower, selectable)
+  uint32_t nifShape = 7;           // MI_RAYLIB_NIF_SHAPE / "nif_shape": 7 = auto (default: K3a where its generated body covers the network, else w6), 6 = a8 (K3a, nif_asm_kernel.hpp),
+                                   // 0 = w6, 1 = t6, 2 = t4 (nif_mlp_kernel's workgroup shapes); 4 = r8, 5 = r8s (K3r, nif_regs_kernel.hpp: measured slower, selectable in the variants build)
   bool coords = true;              // "coords": (pixel, segment) atoms read the pixel coordinates from a compact copy of the stream's (u, v)
   bool nifOverlap = true;          // "nif_overlap": NIF renders trace sample batch b + 1 beside the MLP of batch b (two slot sets, second stream)
   uint32_t nifTraceWgs = 0;        // "nif_trace_wgs": a NIF render's trace launch that runs beside the previous batch's MLP gets at most this many workgroups per
@@ -212,7 +213,7 @@ struct SceneOptions {
     }
     if (key == "nif_shape") {
       const std::string s(v);
-      if (s == "w6") nifShape = 0; else if (s == "t6") nifShape = 1; else if (s == "t4") nifShape = 2; else if (s == "a8") nifShape = 6;
+      if (s == "w6") nifShape = 0; else if (s == "t6") nifShape = 1; else if (s == "t4") nifShape = 2; else if (s == "a8") nifShape = 6; else if (s == "auto") nifShape = 7;
 #if MI_RAYLIB_VARIANTS
       else if (s == "r8") nifShape = 4; else if (s == "r8s") nifShape = 5;
 #else
@@ -999,6 +1000,18 @@ int mi_get_nif_timing(mi_scene* scene, double out[2]) {
       (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
     }
     scene->nifTimes.clear();
+  });
+}
+
+int mi_get_nif_clock(mi_scene* scene, uint64_t out[2]) {
+  if (!scene || !out) { g_err = "mi_get_nif_clock: null argument"; return MI_ERR_INVALID_ARG; }
+  if (!scene->nif.loaded()) { g_err = "mi_get_nif_clock: no NIF model loaded"; return MI_ERR_NO_NIF; }
+  return guarded([&] {
+    HIP_CHECK(hipSetDevice(scene->device));
+    HIP_CHECK(hipDeviceSynchronize());
+    unsigned long long h[2] = {0, 0};
+    HIP_CHECK(hipMemcpy(h, scene->nif.d_clock, sizeof h, hipMemcpyDeviceToHost));
+    out[0] = h[0]; out[1] = h[1];
   });
 }
 
