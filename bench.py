@@ -114,10 +114,10 @@ MEAN_NIF = np.array([-2.3514461517333984, -2.2660605907440186, -1.96489727497100
 MAX_NIF = 3.4299468994140625
 
 
-def config3_record(torch, irl, stream, spp=250):
+def config3_record(torch, irl, stream, spp=1000):
     """BASELINE config 3 (assets/test_scene.dae --load-normals, 1440 x 1440 x 4000 spp) at `spp` samples: one warm-up + one timed
-    launch on a device-resident stream; the frame time scales linearly in the sample count at this length (the
-    segment rule keeps about sixteen work units per pixel), so the 4000-spp figure is quoted as an extrapolation and marked so."""
+    launch on a device-resident stream; from 1000 samples on a pixel's work units are 64-sample segments, so the
+    frame time scales linearly in the sample count and the 4000-spp figure is quoted as an extrapolation, marked so."""
     s = irl.HostScene.import_file(ROOT / "assets" / "test_scene.dae", load_normals=True)
     d = s.desc
     d.set_image(1440, 1440); d.samples_per_pixel = spp; d.path_trace = 1

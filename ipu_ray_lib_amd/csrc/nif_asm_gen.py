@@ -117,7 +117,7 @@ class Emit:
         return out
 
 
-def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4, ko=0, prio=0):
+def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4, ko=0, prio=0, stagger=0, young_prio=0):
     """ko (timing-only builds, results wrong; tools/k3a_lab.py): bit 0 no LDS-DMA, bit 1 no barrier, bit 2 no epilogue, bit 3 no
     fragment reads, bit 4 no waits for fragment reads, bit 5 every second fragment read only. prio: s_setprio for the whole statement."""
     net = Net(kinds, relu)
@@ -200,6 +200,16 @@ def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4, ko=0, prio=0):
     e.i(f"; K3a pass body: layers {kinds}, hidden {32 * HT}, {nsteps} fragments, {nchunks} chunks (generated by nif_asm_gen.py)")
     e.i(f"s_add_u32 s{S_END}, %[ring0], {RING_SLOTS * SLOT}")
     e.i(f"s_mov_b32 s{S_RD}, %[rd]")
+    if stagger or young_prio:
+        # vcc = "this is one of waves 4-7" (the younger wave of its SIMD: a workgroup's waves go to the SIMDs in cyclic order, so
+        # waves w and w + 4 share one); nothing else in the statement touches vcc
+        e.i("s_cmp_ge_u32 %[wavepiece], 4096")
+        e.i("s_cselect_b64 vcc, -1, 0")
+    if young_prio:
+        # one static priority raise for the younger half, no flips (MI355X_MICROARCH.md, Two waves per SIMD, item 4)
+        e.i("s_cbranch_vccz .Lk3a_oldhalf_%=")
+        e.i(f"s_setprio {young_prio}")
+        e.i(".Lk3a_oldhalf_%=:")
     if prio:
         e.i(f"s_setprio {prio}")
     e.i(f"s_add_u32 s{S_SRC0}, %[stream], %[wavepiece]")      # (64-bit operand: its low half; the high half follows)
@@ -265,7 +275,20 @@ def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4, ko=0, prio=0):
         # LDS-DMA pieces of the next chunk at fixed places of this chunk
         cnt_c = net.chunks[c][1]
         places = dma_at if cnt_c == CH else tuple(range(1, 2 * 5, 2))
-        if q in places:
+        if stagger and cnt_c == CH:
+            # the two waves of a SIMD issue their pieces `stagger` fragments apart: an LDS-DMA instruction holds its wave for tens of
+            # cycles, and side by side both waves' MFMAs stop for them
+            if q in places:
+                p = places.index(q)
+                e.i(f"s_cbranch_vccnz .Lk3a_s{si}_%=")
+                dma_piece(c + 1, p)
+                e.i(f".Lk3a_s{si}_%=:")
+            if q - stagger in places:
+                p = places.index(q - stagger)
+                e.i(f"s_cbranch_vccz .Lk3a_t{si}_%=")
+                dma_piece(c + 1, p)
+                e.i(f".Lk3a_t{si}_%=:")
+        elif q in places:
             p = places.index(q)
             dma_piece(c + 1, p)
         # end of a pair: its epilogue goes into the next pair's slots
@@ -275,7 +298,7 @@ def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4, ko=0, prio=0):
             buf ^= 1
     assert not pending_epi
     # the slot of the next pass's chunk 0 (= where this pass's last entry pointed the fetches)
-    if prio:
+    if prio or young_prio:
         e.i("s_setprio 0")
     e.i(f"s_sub_u32 %[rd], s{S_WR}, %[wavepiece]")
     e.i("s_nop 15")
@@ -293,16 +316,18 @@ def main():
     ap.add_argument("--ko", type=int, default=0, help="timing-only knock-outs (results wrong): 1 no LDS-DMA, 2 no barrier, 4 no epilogue, 8 no fragment reads")
     ap.add_argument("--prio", type=int, default=0)
     ap.add_argument("--ring", type=int, default=4, help="fragment ring depth")
+    ap.add_argument("--stagger", type=int, default=0, help="waves 4-7 issue their LDS-DMA pieces this many fragments behind waves 0-3")
+    ap.add_argument("--young-prio", type=int, default=0, help="static s_setprio for waves 4-7")
     a = ap.parse_args()
     set_ring_depth(a.ring)
     relu = [c == "1" for c in (a.relu or "1" * (len(a.kinds) - 1) + "0")]
-    net, lines = generate(a.kinds, relu, tuple(int(x) for x in a.dma_at.split(",")), a.epi_start, a.ko, a.prio)
+    net, lines = generate(a.kinds, relu, tuple(int(x) for x in a.dma_at.split(",")), a.epi_start, a.ko, a.prio, a.stagger, a.young_prio)
     with open(a.out, "w") as f:
         f.write(f"// generated by nif_asm_gen.py --kinds {a.kinds} --relu {''.join('1' if r else '0' for r in relu)}: do not edit\n")
         f.write(f"#define MI_NIF_ASM_KINDS \"{a.kinds}\"\n#define MI_NIF_ASM_RELU \"{''.join('1' if r else '0' for r in relu)}\"\n")
         f.write(f"#define MI_NIF_ASM_CHUNKS {len(net.chunks)}\n#define MI_NIF_ASM_BIAS_FLOATS {net.bias_floats}\n")
         f.write("#define MI_NIF_ASM_CLOBBERS " + ", ".join(f'"v{k}"' for k in range(LAST_VGPR + 1)) + ", " +
-                ", ".join(f'"s{k}"' for k in range(40, 48)) + ', "scc", "memory"\n')
+                ", ".join(f'"s{k}"' for k in range(40, 48)) + ', "vcc", "scc", "memory"\n')
         f.write("#define MI_NIF_ASM_BODY \\\n")
         for ln in lines:
             f.write(f'  "{ln}\\n\\t" \\\n')
