@@ -24,7 +24,7 @@ def main():
     import argparse
     ap = argparse.ArgumentParser()
     ap.add_argument("n", nargs="?", type=int, default=1440 * 1440)
-    ap.add_argument("--shape", default="w6", help="scene option nif_shape: w6 (default) | t6 | t4 (nif_mlp_kernel) | r8 | r8s (K3r, nif_regs_kernel.hpp) | a8 (K3a, nif_asm_kernel.hpp)")
+    ap.add_argument("--shape", default="auto", help="scene option nif_shape: auto (default: K3a for this network) | w6 | t6 | t4 (nif_mlp_kernel) | r8 | r8s (K3r, nif_regs_kernel.hpp) | a8 (K3a, nif_asm_kernel.hpp)")
     ap.add_argument("--reps", type=int, default=5)
     a = ap.parse_args()
     n = a.n
@@ -47,7 +47,7 @@ def main():
     ms = e0.elapsed_time(e1) / reps
     flops_per_ray = 2 * sum(k * c for k, c in dims)
     tf = n * flops_per_ray / (ms * 1e-3) / 1e12
-    print(json.dumps({"kernel": "nif_regs_kernel" if a.shape in ("r8", "r8s") else "nif_asm_kernel" if a.shape == "a8" else "nif_mlp_kernel", "shape": a.shape, "rays": n, "ms": ms, "rays_per_s": n / (ms * 1e-3), "flops_per_ray": flops_per_ray,
+    print(json.dumps({"kernel": "nif_regs_kernel" if a.shape in ("r8", "r8s") else "nif_asm_kernel" if a.shape in ("a8", "auto") else "nif_mlp_kernel", "shape": a.shape, "rays": n, "ms": ms, "rays_per_s": n / (ms * 1e-3), "flops_per_ray": flops_per_ray,
                       "tflops": tf, "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F16_PEAK_TFLOPS}}))
 
 

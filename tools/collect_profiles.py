@@ -80,7 +80,9 @@ if PROBE:
 bench = json.loads((SRC / "bench.json").read_text())
 (DST / f"{TAG}_bench.json").write_text(json.dumps(bench, indent=1))
 report = list(probe_lines)
-for tag, kern in (("c2", "path_trace_wavefront_kernel<false"), ("c3", "path_trace_wavefront_kernel<false"), ("spp16", "path_trace_wavefront_kernel<false"), ("nif", "nif_mlp_kernel")):
+for tag, kern in (("c2", "path_trace_wavefront_kernel<false"), ("c3", "path_trace_wavefront_kernel<false"), ("spp16", "path_trace_wavefront_kernel<false"), ("nif", "nif_asm_kernel" if TAG >= "r05" else "nif_mlp_kernel"), ("nif_w6", "nif_mlp_kernel")):
+    if tag == "nif_w6" and not (SRC / tag).exists():
+        continue
     c = pmc(tag, kern)
     st = stats(tag)
     k = next((r for r in st if kern.split("<")[0] in r["Name"] and ("<false" in r["Name"] or "nif" in r["Name"])), None)
@@ -100,7 +102,9 @@ for tag, kern in (("c2", "path_trace_wavefront_kernel<false"), ("c3", "path_trac
         line += f"HBM {(2 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024 / 1e9:.2f} GB per launch"
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
         cycles = c["GRBM_GUI_ACTIVE"] / 8.0
-        line += f"MFMA busy {c['SQ_VALU_MFMA_BUSY_CYCLES'] / (SIMDS * cycles):.3f}, waiting {c['SQ_WAIT_INST_ANY'] / c['SQ_WAVE_CYCLES']:.3f}, shader clock during the launch {cycles / (float(k['AverageNs']) * 1e-9) / 1e9:.2f} GHz"
+        line += (f"MFMA busy {c['SQ_VALU_MFMA_BUSY_CYCLES'] / (SIMDS * cycles):.3f}, waiting {c['SQ_WAIT_INST_ANY'] / c['SQ_WAVE_CYCLES']:.3f}, shader clock during the launch "
+                 f"{cycles / (float(k['AverageNs']) * 1e-9) / 1e9:.2f} GHz (GRBM_GUI_ACTIVE / 8 / time), LDS instructions per MFMA {c.get('SQ_INSTS_LDS', 0) / max(c.get('SQ_INSTS_MFMA', 1), 1):.3f}, "
+                 f"L2 read requests {c.get('TCP_TCC_READ_REQ_sum', 0):.3e}")
     report.append(line)
     if tag == "c2":
         cycles = c["GRBM_GUI_ACTIVE"] / 8.0
@@ -133,7 +137,7 @@ c5 = json.loads((SRC / "c5_full.json").read_text().strip().splitlines()[0])
 st = stats("c5")
 tot = sum(float(r["TotalDurationNs"]) for r in st) or 1.0
 shares = {r["Name"].split("(")[0][:60]: round(float(r["TotalDurationNs"]) / tot, 4) for r in st if float(r["TotalDurationNs"]) / tot > 0.002}
-mlp = next((r for r in st if "nif_mlp_kernel" in r["Name"]), None)
+mlp = next((r for r in st if "nif_asm_kernel" in r["Name"] or "nif_mlp_kernel" in r["Name"]), None)
 c5["ms_per_frame_4000spp"] = c5["ms_per_sample"] * 4000
 c5["kernel_time_shares_512spp_profiled"] = shares
 if mlp:
