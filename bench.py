@@ -55,8 +55,8 @@ sys.path.insert(0, str(ROOT / "tests"))
 HBM_PEAK_GBS = 8000.0
 L2_PEAK_GBS = 34500.0
 MFMA_F16_PEAK_TFLOPS = 2500.0
-PMC_SUMMARY = ROOT / "profiles" / "r04_pmc_summary.json"   # rocprofv3 --pmc passes of this same command (tools/prof_r04.sh + tools/collect_profiles.py)
-GATHER_PROBE = ROOT / "profiles" / "r04_gather_probe.json"  # tools/gather_probe.py on the same scene (fallback when the probe cannot run in this process)
+PMC_SUMMARY = ROOT / "profiles" / "r05_pmc_summary.json"   # rocprofv3 --pmc passes of this same command (tools/prof_r05.sh + tools/collect_profiles.py)
+GATHER_PROBE = ROOT / "profiles" / "r05_gather_probe.json"  # tools/gather_probe.py on the same scene (fallback when the probe cannot run in this process)
 
 
 def image_shape(n_gpus: int, base: int, weak: bool):
@@ -483,9 +483,9 @@ def main():
     # no figure for that (LDS, L2, HBM and MFMA rates only), so it is MEASURED: csrc/probe/gather_probe.hip performs only
     # the gathers - two global_load_dwordx4 per lane at an index that depends on the node fetched before, a tree-shaped
     # walk over THIS scene's node array, K1w's launch shape (256-thread workgroups, 6 per CU), as many of a wave's 64
-    # lanes active as K1w's box-test turns have - and its rate (TA busy 0.99: profiles/r04_gather_probe_pmc.txt) is the
+    # lanes active as K1w's box-test turns have - and its rate (TA busy 0.99: profiles/r05_gather_probe_pmc.txt) is the
     # peak; `frac` = K1w's gathers per second / the probe's. In this run when the probe library is there, else from
-    # profiles/r04_gather_probe.json.
+    # profiles/r05_gather_probe.json.
     roof = {"kernel": "path_trace_wavefront_kernel", "avg_launch_ms": avg_kernel_s * 1e3}
     if not args.no_extras:
         probe_desc = irl.SceneDesc.from_buffer_copy(d)

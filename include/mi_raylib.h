@@ -242,6 +242,8 @@ int mi_scene_set_ray_batch(mi_scene* scene, size_t rays_per_batch);
  *   "nif_trace_wgs" 0..16           with nif_overlap: workgroups per compute unit of a trace launch that runs beside the previous batch's MLP
  *                                   (0 = all that stay resident, the default)
  *   "nif_timing"    0 | 1           bracket every MLP launch of a NIF render with HIP events (mi_get_nif_timing)
+ *   "leaf_rot"      0 | 1           scenes without vertex normals: the default kernel reads primitive records pre-rotated for the cast's shear axis (default 1)
+ *   "lean_hit"      0 | 1           scenes without vertex normals run the build of the default kernel that carries no barycentrics (default 1)
  *   "coords"        0 | 1           (pixel, segment) work units read the pixel's (u, v) from a compact copy of the stream gathered once
  *                                   per launch, not from the 84-byte record (default 1: a third of the HBM traffic)
  *   "cus"           0..4096         compute units the launch grids are sized for (0 = what the device reports; grids are

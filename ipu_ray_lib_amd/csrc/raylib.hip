@@ -111,6 +111,8 @@ struct SceneOptions {
   bool pin = true;                 // MI_RAYLIB_PIN / "pin": page-lock the caller's stream for the duration of mi_render
   uint32_t nifShape = 7;           // MI_RAYLIB_NIF_SHAPE / "nif_shape": 7 = auto (default: K3a where its generated body covers the network, else w6), 6 = a8 (K3a, nif_asm_kernel.hpp),
                                    // 0 = w6, 1 = t6, 2 = t4 (nif_mlp_kernel's workgroup shapes); 4 = r8, 5 = r8s (K3r, nif_regs_kernel.hpp: measured slower, selectable in the variants build)
+  bool leafRot = true;             // "leaf_rot": scenes without vertex normals read primitive records pre-rotated for the cast's shear axis (GLeafRot: 18 selects per triangle test become 6; -2.4 %, profiles/r05_k1w_leaf_ab.txt)
+  bool leanHit = true;             // "lean_hit": scenes without vertex normals run the default kernel's build that carries no barycentrics (BARY = false)
   bool coords = true;              // "coords": (pixel, segment) atoms read the pixel coordinates from a compact copy of the stream's (u, v)
   bool nifOverlap = true;          // "nif_overlap": NIF renders trace sample batch b + 1 beside the MLP of batch b (two slot sets, second stream)
   uint32_t nifTraceWgs = 0;        // "nif_trace_wgs": a NIF render's trace launch that runs beside the previous batch's MLP gets at most this many workgroups per
@@ -196,6 +198,8 @@ struct SceneOptions {
     if (key == "nif_overlap") return flag01(v, nifOverlap);
     if (key == "nif_trace_wgs") { if (!number(v, 0, 16, q)) return false; nifTraceWgs = (uint32_t)q; return true; }
     if (key == "coords") return flag01(v, coords);
+    if (key == "lean_hit") return flag01(v, leanHit);
+    if (key == "leaf_rot") return flag01(v, leafRot);
     if (key == "double_fallback") {
       bool b = doubleFallback;
       if (!flag01(v, b)) return false;
@@ -466,6 +470,23 @@ void buildDeviceScene(mi_scene& S, const mi_scene_desc& d) {
   DeviceScene& ds = S.ds;
   ds.nodes = S.keep(upload(nodes)); ds.numNodes = N;
   ds.leaves = S.keep(upload(leaves)); ds.numLeaves = (uint32_t)leaves.size();
+  {
+    // the primitive-test part of every record once per shear axis (GLeafRot, trace_kernels.hpp): a triangle's vertices with their
+    // components rotated so that component kz comes last - (kx, ky, kz) = (kz + 1, kz + 2, kz) mod 3, permute_kz - other records as they are
+    std::vector<GLeafRot> rot(leaves.size());
+    memset(rot.data(), 0, rot.size() * sizeof(GLeafRot));
+    for (size_t i = 0; i < leaves.size(); ++i)
+      for (uint32_t kz = 0; kz < 3; ++kz) {
+        GLeafBlock& B = rot[i].b[kz];
+        B.type = leaves[i].type;
+        for (int q = 0; q < 9; ++q) B.f[q] = leaves[i].f[q];
+        if (leaf_kind(leaves[i]) == LEAF_TRI) {
+          const uint32_t kx = (kz + 1) % 3, ky = (kz + 2) % 3;
+          for (int v = 0; v < 3; ++v) { B.f[3 * v] = leaves[i].f[3 * v + kx]; B.f[3 * v + 1] = leaves[i].f[3 * v + ky]; B.f[3 * v + 2] = leaves[i].f[3 * v + kz]; }
+        }
+      }
+    ds.leavesRot = S.keep(upload(rot));
+  }
   ds.matIDs = S.keep(upload(std::vector<uint32_t>(d.mat_ids, d.mat_ids + d.num_mat_ids)));
   ds.materials = S.keep(upload(std::vector<mi_material>(d.materials, d.materials + d.num_materials)));
   ds.numMaterials = d.num_materials;
@@ -712,8 +733,16 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
     } else if (!STATS && S.opt.wavesPerSimd == 6) {
       // the default path: SHADE and GEN in one turn, 80 VGPRs without a spill, six waves per SIMD (profiles/r04_k1w_merged_turn_ab.txt);
       // the default scheduling weights are compiled into the two instantiations (plain renders / NIF slots)
-      if (plain) go(path_trace_wavefront_kernel<false, false, 256, 6, false, 0, true>);
-      else go(path_trace_wavefront_kernel<false, false, 256, 6, false, 1, true>);
+      // the builds of the default form: a scene WITHOUT vertex normals takes the one that carries no barycentrics (option "lean_hit")
+      // and reads the primitive records pre-rotated for the cast's shear axis (option "leaf_rot"); both default on, both exact (every
+      // byte the oracle's either way), the other settings kept for A/B. With vertex normals the pre-rotated form spills seven
+      // registers at 80 and loses 8 % (test_scene.dae: 292 against 271 ms per 1000 spp, profiles/r05_k1w_leaf_ab.txt): not built.
+      const bool lean = S.opt.leanHit && !S.ds.hasNormals;
+      const bool rot = lean && S.opt.leafRot && S.ds.leavesRot != nullptr;
+#define MI_K1W(SL, BA, RO) path_trace_wavefront_kernel<false, false, 256, 6, false, SL, true, false, false, true, BA, RO>
+      if (plain) { if (rot) go(MI_K1W(0, false, true)); else if (lean) go(MI_K1W(0, false, false)); else go(MI_K1W(0, true, false)); }
+      else { if (rot) go(MI_K1W(1, false, true)); else if (lean) go(MI_K1W(1, false, false)); else go(MI_K1W(1, true, false)); }
+#undef MI_K1W
     } else {
       go(path_trace_wavefront_kernel<STATS, false, 256>);               // the instrumented build (and, in the variants build, option waves = 4)
     }

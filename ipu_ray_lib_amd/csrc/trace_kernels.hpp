@@ -56,9 +56,18 @@ static_assert(sizeof(GLeaf) == 64, "GLeaf must stay 64 bytes");
 __host__ __device__ __forceinline__ uint32_t leaf_kind(const GLeaf& L) { return L.type & 0xFFFFu; }
 __host__ __device__ __forceinline__ uint32_t leaf_geom(const GLeaf& L) { return L.type >> 16; }
 
+// Round 5 (scene option "leaf_rot", default on: profiles/r05_k1w_leaf_ab.txt): the primitive-test part of a leaf record once per
+// shear axis. Block kz = {type, nine floats}: a triangle's vertices with their components rotated so that component kz
+// comes last - (p - o) permuted equals permuted p - permuted o component for component, so the test's 18 selects on the vertices
+// become 6 on the origin -, a sphere's or disc's floats as they are. 128 bytes per node (indexed like leaves[]).
+struct __attribute__((aligned(8))) GLeafBlock { uint32_t type; float f[9]; };
+struct __attribute__((aligned(128))) GLeafRot { GLeafBlock b[3]; uint32_t pad[2]; };
+static_assert(sizeof(GLeafBlock) == 40 && sizeof(GLeafRot) == 128, "GLeafRot: three 40-byte blocks in a 128-byte line");
+
 struct DeviceScene {
   const GNode* nodes;        uint32_t numNodes;
   const GLeaf* leaves;       uint32_t numLeaves;
+  const GLeafRot* leavesRot;     // the same records' primitive-test part, pre-rotated per shear axis
   const uint32_t* matIDs;    // per geomID
   const mi_material* materials; uint32_t numMaterials;
   // vertex normals (only when the scene was loaded with normals)
@@ -149,9 +158,10 @@ __device__ __forceinline__ f3 permute_kz(f3 p, uint32_t kz) {
 // +inf (det>0), and "tScaled < -inf" / "tScaled > +inf" are false for every float including NaN, so those two
 // comparisons of Mesh.cpp:62-66 drop out exactly. Measured against the early-return form: -1.4 % frame time (hipcc
 // turns early returns into nested exec regions whose merges cost 45 register moves per test).
-template <bool DF = false>
+// PRE: p0, p1, p2 and o arrive with their components already rotated for sh.kz (GLeafRot)
+template <bool DF = false, bool PRE = false>
 __device__ __forceinline__ float intersect_triangle(f3 p0, f3 p1, f3 p2, f3 o, const Shear& sh, float& b0, float& b1, float& b2) {
-  f3 p0t = permute_kz(p0 - o, sh.kz), p1t = permute_kz(p1 - o, sh.kz), p2t = permute_kz(p2 - o, sh.kz);
+  f3 p0t = PRE ? p0 - o : permute_kz(p0 - o, sh.kz), p1t = PRE ? p1 - o : permute_kz(p1 - o, sh.kz), p2t = PRE ? p2 - o : permute_kz(p2 - o, sh.kz);
   p0t.x += sh.sx * p0t.z; p0t.y += sh.sy * p0t.z;
   p1t.x += sh.sx * p1t.z; p1t.y += sh.sy * p1t.z;
   p2t.x += sh.sx * p2t.z; p2t.y += sh.sy * p2t.z;

@@ -115,7 +115,12 @@ constexpr WaveTune kDefaultTune = {8, 16, 24, 48, 3, 4, 6, 1, 1, 40, 0};      //
 // DF: the reference's ALLOW_DOUBLE_FALLBACK=1 build of the triangle test (trace_kernels.hpp). FAST: the tolerance tier
 // (scene option "fast"): the box test as three pairs of FMAs on (plane, 1/d, -o/d), the triangle test contracted, no
 // literal NaN-exact fallback - results within a stated tolerance of the exact tier's, not bit-identical.
-template <bool STATS, bool LDS_NODES, int BLOCK, int WAVES_PER_SIMD = 4, bool SPEC = false, int SLOTS = 2, bool FIXED_TUNE = false, bool DF = false, bool FAST = false, bool MERGE = true>
+// BARY = false (round 5): for scenes WITHOUT vertex normals. The barycentrics of the closest hit only ever feed the interpolated
+// normal (Mesh.hpp:115-120); a scene without vertex normals shades with the face normal, so the three products per primitive test,
+// the three selects of the closest-hit update and three registers of the walk are dead weight there. Bit-identical by construction
+// (nothing reads them); launchWavefront picks it by the scene's hasNormals.
+template <bool STATS, bool LDS_NODES, int BLOCK, int WAVES_PER_SIMD = 4, bool SPEC = false, int SLOTS = 2, bool FIXED_TUNE = false, bool DF = false, bool FAST = false, bool MERGE = true,
+          bool BARY = true, bool ROT = false>
 __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? WAVES_PER_SIMD : 1) path_trace_wavefront_kernel(DeviceScene sc, mi_trace_result* rays, uint32_t n,
                                                                    uint32_t* workCounter, uint32_t ldsNodeCount, WaveTune tuneArg, uint32_t tileStreamW, WaveExtras ex) {
   const WaveTune tune = FIXED_TUNE ? kDefaultTune : tuneArg;
@@ -483,11 +488,22 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
             if (STATS) cs.leaves++;
             const uint32_t atLeaf = (node >> 5) - 1u;   // the leaf the lane stopped at (its link is the node after it)
             // (uniform base + 32-bit byte offset, as for the nodes: a 64-byte record per 32-byte node)
-            const GLeaf L = *reinterpret_cast<const GLeaf*>(reinterpret_cast<const char*>(sc.leaves) + ((node - 32u) << 1));
+            GLeaf L;
+            if constexpr (ROT) {
+              // the block of the cast's shear axis: the same three loads (16 + 16 + 8 bytes), the vertices arrive rotated
+              const GLeafBlock B = *reinterpret_cast<const GLeafBlock*>(reinterpret_cast<const char*>(sc.leavesRot) + ((node - 32u) << 2) + sh.kz * 40u);
+              L.type = B.type;
+#pragma unroll
+              for (int q = 0; q < 9; ++q) L.f[q] = B.f[q];
+            } else {
+              L = *reinterpret_cast<const GLeaf*>(reinterpret_cast<const char*>(sc.leaves) + ((node - 32u) << 1));
+            }
             float t, b0 = 0.f, b1 = 0.f, b2 = 0.f;
             bool cand;
             const uint32_t kind = leaf_kind(L);
             if (kind == LEAF_TRI) {
+              if constexpr (ROT) t = intersect_triangle<DF, true>(mk(L.f[0], L.f[1], L.f[2]), mk(L.f[3], L.f[4], L.f[5]), mk(L.f[6], L.f[7], L.f[8]), permute_kz(o, sh.kz), sh, b0, b1, b2);
+              else
               t = FAST ? intersect_triangle_fast(mk(L.f[0], L.f[1], L.f[2]), mk(L.f[3], L.f[4], L.f[5]), mk(L.f[6], L.f[7], L.f[8]), o, sh, b0, b1, b2)
                        : intersect_triangle<DF>(mk(L.f[0], L.f[1], L.f[2]), mk(L.f[3], L.f[4], L.f[5]), mk(L.f[6], L.f[7], L.f[8]), o, sh, b0, b1, b2);
               cand = t > 0.f && t < kInf;
@@ -501,7 +517,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
             // (five selects on one mask: as an if-block hipcc copies the five values out, branches, and copies them back)
             const bool closer = cand & (t > 0.f) & (t < hit.t);
             hit.t = closer ? t : hit.t; hit.leaf = closer ? atLeaf : hit.leaf;
-            hit.b0 = closer ? b0 : hit.b0; hit.b1 = closer ? b1 : hit.b1; hit.b2 = closer ? b2 : hit.b2;
+            if constexpr (BARY) { hit.b0 = closer ? b0 : hit.b0; hit.b1 = closer ? b1 : hit.b1; hit.b2 = closer ? b2 : hit.b2; }
             ph = (node >= numNodes) ? PH_SHADE : PH_NODE;
           }
           // every lane that waited for a primitive test is walking again: the next vote would pick NODE anyway,

@@ -547,7 +547,7 @@ static oleafhit leaf_intersect(const oscene* sc, uint32_t geomID, uint32_t primI
 /* ------------------------------------------------------------------------- */
 /* CompactBvh::intersect / ::occluded (CompactBvh.hpp:33-139)       [UNPINNED vs reference
  * outputs: no reference-produced traversal result exists; pinned structurally by the
- * brute-force cross-check in tests/test_oracle_bvh.py] */
+ * brute-force cross-check in tests/test_oracle_pins.py::test_bvh_queries_against_brute_force] */
 /* ------------------------------------------------------------------------- */
 #define O_MAX_STACK 128
 
