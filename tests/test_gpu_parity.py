@@ -1011,6 +1011,35 @@ def test_launch_grids_follow_the_compute_unit_count(scenes):
             irl.IpuScene(d).set_option("nif_generations", 0)
 
 
+def test_default_kernel_builds_lean_hit_and_leaf_rot_bit_exact(scenes):
+    """Round 5's two builds of the default kernel for scenes without vertex normals - no barycentrics in the walk (option lean_hit),
+    primitive records read pre-rotated for the cast's shear axis (option leaf_rot: rotated p - permuted o is (p - o) permuted,
+    component for component) - against the oracle in every combination, on the box scene (triangles, spheres, a disc) at a
+    segmented sample count and on a ragged crop; a NIF render (slot mode: its own instantiations) must agree with itself across the
+    combinations byte for byte."""
+    s = scenes["box"]
+    with _desc_restored(s.desc) as d:
+        d.set_image(150, 90, (131, 77, 7, 3)); d.samples_per_pixel = 70; d.path_trace = 1
+        want = s.init_ray_stream(); ol.path_trace_pixel_rng(d, want, 16)
+        for lean, rot in ((1, 1), (1, 0), (0, 1), (0, 0)):
+            dev = irl.IpuScene(d).set_option("lean_hit", lean).set_option("leaf_rot", rot)
+            got = s.init_ray_stream(); dev.run(got, irl.MODE_PATH_TRACE); dev.close()
+            assert_streams_identical(got, want, f"lean_hit={lean}, leaf_rot={rot}")
+    sp = scenes["spheres"]
+    with _desc_restored(sp.desc) as d:
+        rng = np.random.default_rng(21)
+        ks, bs, relu = _nif_weights(rng, hidden=64, embed=12, layers=3)
+        d.set_image(96, 64); d.samples_per_pixel = 20; d.path_trace = 1
+        frames = []
+        for lean, rot in ((1, 1), (1, 0), (0, 0)):
+            dev = irl.IpuScene(d).set_option("lean_hit", lean).set_option("leaf_rot", rot)
+            dev.setNif(ks, bs, relu, 12, 3.43, np.array([-2.35, -2.26, -1.96], np.float32), True)
+            got = sp.init_ray_stream(); dev.run(got, irl.MODE_PATH_TRACE); dev.close()
+            frames.append(got)
+        assert_streams_identical(frames[1], frames[0], "NIF render, leaf_rot off")
+        assert_streams_identical(frames[2], frames[0], "NIF render, lean_hit and leaf_rot off")
+
+
 def test_work_units_fetch_coordinates_from_the_compact_copy_or_the_records(scenes):
     """(pixel, segment) work units read the pixel's (row, col) from a compact copy of the stream gathered once per launch
     (option "coords", default on) or, with the option off, from the 84-byte records as up to round 3: either way every
