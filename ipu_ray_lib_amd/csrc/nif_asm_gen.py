@@ -41,6 +41,7 @@ CH = 4 * HT                  # fragments per chunk
 SLOT = CH * 1024
 RING_SLOTS = 3
 D = 4                        # fragment ring depth (set_ring_depth)
+NW = 8                       # waves per workgroup (tools/k3a_lab.py also times a 4-wave form: one wave per SIMD)
 
 SETA, SETB, ACC, RING = 0, 80, 160, 192
 BIAS, VADDR, LAST_VGPR = RING + 4 * D, RING + 4 * D + 8, RING + 4 * D + 8
@@ -117,10 +118,60 @@ class Emit:
         return out
 
 
-def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4, ko=0, prio=0, stagger=0, young_prio=0):
+class Lay:
+    """Where things live, for the two workgroup shapes.
+    K3a (MT = 2 ray tiles per wave, 8 waves = two per SIMD, 256 registers): everything in architectural registers (header).
+    K3b (MT = 4, 4 waves = one per SIMD, 512 registers = 256 architectural + 256 accumulator-file): activation set A in v[0:159], set
+    B in a[0:159] (an MFMA takes its B operand from either file; a layer that writes set B converts into temporaries and moves them
+    with v_accvgpr_write), accumulators v[160:223] (two buffers of [tile][ray tile][4]), eight temporaries v[224:231], the chunk address
+    v232, the fragment ring a[160:175] (ds_read_b128 fills accumulator-file registers directly; an MFMA reads its A operand from
+    them). An MFMA's C and D operands share one file, so there is no bias register: a pair's accumulators are LOADED with the bias
+    (ds_read_b128 into the accumulator, one per tile and ray tile, issued as soon as the buffer's previous pair has been converted)
+    and every MFMA accumulates. Every A fragment read from LDS feeds FOUR MFMAs: half K3a's LDS bytes per MFMA."""
+
+    def __init__(self, mt, nw):
+        self.mt, self.nw = mt, nw
+        if mt == 2:
+            self.acc_stride = 16
+            self.last_v, self.last_a = LAST_VGPR, -1
+        else:
+            self.acc_stride = 32
+            self.last_v, self.last_a = 232, 175
+
+    def reg(self, f, base, n=4):
+        return f"{f}[{base}:{base + n - 1}]" if n > 1 else f"{f}{base}"
+
+    def act(self, which, ks, m):            # which: 0 = set A, 1 = set B -> (file, first register) of k-step ks, ray tile m
+        if self.mt == 2:
+            return ("v", (SETA if which == 0 else SETB) + 8 * ks + 4 * m)
+        return ("v" if which == 0 else "a", 16 * ks + 4 * m)
+
+    def acc(self, buf, tt, m):
+        return ("v", ACC + self.acc_stride * buf + 4 * (self.mt * tt + m))
+
+    def ring(self, i):
+        return ("v", RING + 4 * i) if self.mt == 2 else ("a", 160 + 4 * i)
+
+    def bias(self, tt):
+        return ("v", BIAS + 4 * tt) if self.mt == 2 else ("a", 176 + 4 * tt)
+
+    def vaddr(self):
+        return VADDR if self.mt == 2 else 232
+
+    def tmp(self, k):
+        return 224 + k
+
+    def clobbers(self):
+        return ([f'"v{k}"' for k in range(self.last_v + 1)] + [f'"a{k}"' for k in range(self.last_a + 1)] +
+                [f'"s{k}"' for k in range(40, 48)] + ['"vcc"', '"scc"', '"memory"'])
+
+
+def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4, ko=0, prio=0, stagger=0, young_prio=0, mt=2):
     """ko (timing-only builds, results wrong; tools/k3a_lab.py): bit 0 no LDS-DMA, bit 1 no barrier, bit 2 no epilogue, bit 3 no
-    fragment reads, bit 4 no waits for fragment reads, bit 5 every second fragment read only. prio: s_setprio for the whole statement."""
+    fragment reads, bit 4 no waits for fragment reads, bit 5 every second fragment read only. prio: s_setprio for the whole statement.
+    mt: ray tiles per wave (2 = K3a; 4 = K3b, which wants NW = 4)."""
     net = Net(kinds, relu)
+    L = Lay(mt, NW)
     e = Emit()
     nchunks = len(net.chunks)
     # the fragments a wave really consumes, in order, with their chunk and place in it
@@ -131,12 +182,13 @@ def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4, ko=0, prio=0, 
             if f is not None:
                 steps.append(dict(l=f[0], j=f[1], ks=f[2], tt=f[3], c=c, q=q))
     nsteps = len(steps)
+    VA = L.vaddr()
 
-    def in_set(l):       # the set layer l READS (layer 0 reads the features)
-        return SETA if l % 2 == 1 else SETB
+    def in_which(l):       # the set layer l READS (layer 0 reads the features): 0 = A, 1 = B
+        return 0 if l % 2 == 1 else 1
 
-    def out_set(l):
-        return SETA if l % 2 == 0 else SETB
+    def out_which(l):
+        return 0 if l % 2 == 0 else 1
 
     def chunk_entry(c, first_of_pass=False):
         """In front of the first READ of chunk c: the wave's LDS-DMA pieces of it have landed, every wave says so, nobody reads
@@ -155,16 +207,16 @@ def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4, ko=0, prio=0, 
         e.i(f"s_cmp_lt_u32 s{S_T2}, s{S_END}")
         e.i(f"s_cselect_b32 s{S_WR}, s{S_T2}, %[ring0]")
         e.i(f"s_add_u32 s{S_WR}, s{S_WR}, %[wavepiece]")
-        e.i(f"v_add_u32 v{VADDR}, s{S_RD}, %[lane16]")
+        e.i(f"v_add_u32 v{VA}, s{S_RD}, %[lane16]")
 
     def dma_piece(c_next, p):
         first, cnt = net.chunks[c_next % nchunks]
-        if 8 * p >= cnt or ko & 1:
+        if NW * p >= cnt or ko & 1:
             return
-        e.i(f"; LDS-DMA: chunk {c_next % nchunks}{' of the next pass' if c_next >= nchunks else ''}, piece wave + {8 * p}")
-        e.i(f"s_add_u32 s{S_T0}, s{S_SRC0}, {(first + 8 * p) * 1024}")
+        e.i(f"; LDS-DMA: chunk {c_next % nchunks}{' of the next pass' if c_next >= nchunks else ''}, piece wave + {NW * p}")
+        e.i(f"s_add_u32 s{S_T0}, s{S_SRC0}, {(first + NW * p) * 1024}")
         e.i(f"s_addc_u32 s{S_T1}, s{S_SRC1}, 0")
-        e.i(f"s_add_u32 m0, s{S_WR}, {8 * p * 1024}")
+        e.i(f"s_add_u32 m0, s{S_WR}, {NW * p * 1024}")
         e.i("s_nop 0")
         e.i(f"global_load_lds_dwordx4 %[lane16], s[{S_T0}:{S_T1}]")
 
@@ -172,32 +224,53 @@ def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4, ko=0, prio=0, 
         s = steps[si]
         if ko & 8 or (ko & 32 and si % 2 == 1):
             return
+        text = f"ds_read_b128 {L.reg(*L.ring(si % D))}, v{VA} offset:{s['q'] * 1024}"
         if ko & 16:
-            e.i(f"ds_read_b128 {vr(RING + 4 * (si % D))}, v{VADDR} offset:{s['q'] * 1024}")
+            e.i(text)
             return
-        e.read(("ring", si), f"ds_read_b128 {vr(RING + 4 * (si % D))}, v{VADDR} offset:{s['q'] * 1024}")
+        e.read(("ring", si), text)
 
     def bias_read(l, j):
         tiles = (0,) if net.kinds[l] in "LM" else (2 * j, 2 * j + 1)
         for t, tile in enumerate(tiles):
-            e.read(("bias", l, j, t), f"ds_read_b128 {vr(BIAS + 4 * t)}, %[biasv] offset:{4 * net.bias_base[l] + 64 * tile}")
+            e.read(("bias", l, j, t), f"ds_read_b128 {L.reg(*L.bias(t))}, %[biasv] offset:{4 * net.bias_base[l] + 64 * tile}")
+
+    # K3b: the pairs of a pass in order, and the load of a pair's bias INTO its accumulators (C and D of an MFMA share a file)
+    pairs = []
+    for l, k in enumerate(net.kinds):
+        pairs += [(l, 0)] if k in "LM" else [(l, j) for j in range(HT)]
+
+    def bias_into_acc(pi, buf_):
+        if pi >= len(pairs):
+            return
+        l, j = pairs[pi]
+        lastl = net.kinds[l] in "LM"
+        tiles = (0,) if lastl else (2 * j, 2 * j + 1)
+        for t, tile in enumerate(tiles):
+            for m in range(mt):
+                dst = f"%[o{m}]" if lastl else L.reg(*L.acc(buf_, t, m))
+                e.read(("biasacc", pi, t, m), f"ds_read_b128 {dst}, %[biasv] offset:{4 * net.bias_base[l] + 64 * tile}")
 
     def epilogue(l, j, buf):
-        o = out_set(l)
         ins = []
-        for m in (0, 1):
-            dst = o + 8 * j + 4 * m
+        for m in range(mt):
+            f, dst = L.act(out_which(l), j, m)
+            # (an accumulator-file destination: convert into temporaries, ReLU there, move)
+            tgt = [dst + k for k in range(4)] if f == "v" else [L.tmp(4 * (m % 2) + k) for k in range(4)]
             for t in (0, 1):
-                a = ACC + 16 * buf + 4 * (2 * t + m)
-                ins.append(f"v_cvt_pk_f16_f32 v{dst + 2 * t}, v{a}, v{a + 1}")
-                ins.append(f"v_cvt_pk_f16_f32 v{dst + 2 * t + 1}, v{a + 2}, v{a + 3}")
+                a = L.acc(buf, t, m)[1]
+                ins.append(f"v_cvt_pk_f16_f32 v{tgt[2 * t]}, v{a}, v{a + 1}")
+                ins.append(f"v_cvt_pk_f16_f32 v{tgt[2 * t + 1]}, v{a + 2}, v{a + 3}")
             if net.relu[l]:
                 for k in range(4):
-                    ins.append(f"v_pk_max_f16 v{dst + k}, v{dst + k}, 0")
+                    ins.append(f"v_pk_max_f16 v{tgt[k]}, v{tgt[k]}, 0")
+            if f == "a":
+                for k in range(4):
+                    ins.append(f"v_accvgpr_write_b32 a{dst + k}, v{tgt[k]}")
         return ins
 
     # ---------------------------------------------------------------- the pass
-    e.i(f"; K3a pass body: layers {kinds}, hidden {32 * HT}, {nsteps} fragments, {nchunks} chunks (generated by nif_asm_gen.py)")
+    e.i(f"; K3{'a' if mt == 2 else 'b'} pass body: layers {kinds}, hidden {32 * HT}, {nsteps} fragments, {nchunks} chunks, {NW} waves x {mt} ray tiles (generated by nif_asm_gen.py)")
     e.i(f"s_add_u32 s{S_END}, %[ring0], {RING_SLOTS * SLOT}")
     e.i(f"s_mov_b32 s{S_RD}, %[rd]")
     if stagger or young_prio:
@@ -218,12 +291,16 @@ def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4, ko=0, prio=0, 
     for si in range(min(D, nsteps)):
         assert steps[si]["c"] == 0
         ring_read(si)
-    bias_read(0, 0)
+    if mt == 2:
+        bias_read(0, 0)
+    else:
+        bias_into_acc(0, 0)       # (pair 1's goes out behind pair 0's first k-step: lgkmcnt holds 15)
 
-    pending_epi = []            # VALU of the previous pair, dealt one per MFMA slot from slot `epi_start` of the next pair on
+    pending_epi = []            # VALU of the previous pair, dealt over the MFMA slots of the next pair from slot `epi_start` on
     pair_slot = 0               # MFMAs issued in the current pair
     buf = 0
-    dma_next = {}               # chunk -> next piece
+    pair_i = -1                 # index into `pairs`
+    epi_buf = None              # K3b: the buffer the pending epilogue reads (free for the pair after next once it is dealt)
     for si, s in enumerate(steps):
         l, j, ks, tt, c, q = s["l"], s["j"], s["ks"], s["tt"], s["c"], s["q"]
         kind = net.kinds[l]
@@ -231,26 +308,29 @@ def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4, ko=0, prio=0, 
         KS = net.ks[l]
         if ks == 0 and tt == 0:
             pair_slot = 0
+            pair_i += 1
         if not ko & 16:
             e.wait(("ring", si))
-        if ks == 0:
+        if ks == 0 and mt == 2:
             e.wait(("bias", l, j, tt))
-        for m in (0, 1):
+        for m in range(mt):
             # B operand: the layer's input k-step, or a feature k-step
             act_steps = 0 if kind == "F" else HT
             if ks < act_steps:
-                b = vr(in_set(l) + 8 * ks + 4 * m)
+                b = L.reg(*L.act(in_which(l), ks, m))
             else:
                 b = f"%[f{ks - act_steps}{m}]"
             if last:
                 d_ = f"%[o{m}]"
             else:
-                d_ = vr(ACC + 16 * buf + 4 * (2 * tt + m))
-            c_ = vr(BIAS + 4 * tt) if ks == 0 else d_
-            e.i(f"v_mfma_f32_16x16x32_f16 {d_}, {vr(RING + 4 * (si % D))}, {b}, {c_}")
+                d_ = L.reg(*L.acc(buf, tt, m))
+            c_ = L.reg(*L.bias(tt)) if (ks == 0 and mt == 2) else d_
+            if ks == 0 and mt != 2:
+                e.wait(("biasacc", pair_i, tt, m))
+            e.i(f"v_mfma_f32_16x16x32_f16 {d_}, {L.reg(*L.ring(si % D))}, {b}, {c_}")
             pair_slot += 1
             # fillers behind this MFMA
-            if m == 1:
+            if m == mt - 1:
                 nxt = si + D
                 if nxt < nsteps:
                     if steps[nxt]["c"] != steps[nxt - 1]["c"]:
@@ -259,22 +339,28 @@ def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4, ko=0, prio=0, 
             if pending_epi and pair_slot > epi_start:
                 # the previous pair's epilogue is dealt over the FIRST HALF of this pair's MFMAs (all of them when the pair is
                 # short): its values are the next layer's operands from that layer's k-step j on, and the final layer reads the
-                # last pair's output in its last two MFMAs
-                total = 2 * KS if last else 4 * KS
-                until = total if total <= 8 else total // 2
+                # last pair's output in its last MFMAs
+                total = (mt * KS) if last else (2 * mt * KS)
+                until = total if total <= 4 * mt else total // 2
                 per = max(1, -(-len(pending_epi) // max(1, until - pair_slot + 1)))
                 for _ in range(min(per, len(pending_epi))):
                     e.i(pending_epi.pop(0))
+                if mt != 2 and not pending_epi and epi_buf is not None:
+                    # the buffer of the pair before this one is converted: the pair after this one loads its bias into it
+                    bias_into_acc(pair_i + 1, epi_buf)
+                    epi_buf = None
         # the NEXT pair's bias, as soon as this pair's first MFMAs (which take the bias as C) have issued
         is_pair_first_done = (ks == 0 and (tt == 1 or last))
-        if is_pair_first_done:
+        if is_pair_first_done and mt != 2 and pair_i == 0:
+            bias_into_acc(1, 1)
+        if is_pair_first_done and mt == 2:
             if not last and j + 1 < HT:
                 bias_read(l, j + 1)
             elif l + 1 < len(net.kinds) and not last:
                 bias_read(l + 1, 0)
         # LDS-DMA pieces of the next chunk at fixed places of this chunk
         cnt_c = net.chunks[c][1]
-        places = dma_at if cnt_c == CH else tuple(range(1, 2 * 5, 2))
+        places = (dma_at if NW == 8 else tuple(range(1, 31, 3))) if cnt_c == CH else (tuple(range(1, 2 * 5, 2)) if NW == 8 else tuple(range(10)))
         if stagger and cnt_c == CH:
             # the two waves of a SIMD issue their pieces `stagger` fragments apart: an LDS-DMA instruction holds its wave for tens of
             # cycles, and side by side both waves' MFMAs stop for them
@@ -295,6 +381,9 @@ def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4, ko=0, prio=0, 
         if not last and ks == KS - 1 and tt == 1:
             assert not pending_epi, "the previous pair's epilogue did not fit"
             pending_epi = [] if ko & 4 else epilogue(l, j, buf)
+            epi_buf = buf
+            if ko & 4 and mt != 2:
+                bias_into_acc(pair_i + 2, buf); epi_buf = None
             buf ^= 1
     assert not pending_epi
     # the slot of the next pass's chunk 0 (= where this pass's last entry pointed the fetches)
@@ -303,6 +392,7 @@ def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4, ko=0, prio=0, 
     e.i(f"s_sub_u32 %[rd], s{S_WR}, %[wavepiece]")
     e.i("s_nop 15")
     e.i("s_nop 15")
+    generate.layout = L
     return net, e.render()
 
 
@@ -316,19 +406,24 @@ def main():
     ap.add_argument("--ko", type=int, default=0, help="timing-only knock-outs (results wrong): 1 no LDS-DMA, 2 no barrier, 4 no epilogue, 8 no fragment reads")
     ap.add_argument("--prio", type=int, default=0)
     ap.add_argument("--ring", type=int, default=4, help="fragment ring depth")
+    ap.add_argument("--waves", type=int, default=8, help="waves per workgroup (4: one wave per SIMD)")
+    ap.add_argument("--tag", default="", help="suffix of the macro names written (nif_asm_kernel.hpp includes one body per workgroup shape)")
+    ap.add_argument("--mt", type=int, default=2, help="ray tiles per wave: 2 (K3a, with --waves 8) or 4 (K3b, with --waves 4)")
     ap.add_argument("--stagger", type=int, default=0, help="waves 4-7 issue their LDS-DMA pieces this many fragments behind waves 0-3")
     ap.add_argument("--young-prio", type=int, default=0, help="static s_setprio for waves 4-7")
     a = ap.parse_args()
     set_ring_depth(a.ring)
+    global NW
+    NW = a.waves
     relu = [c == "1" for c in (a.relu or "1" * (len(a.kinds) - 1) + "0")]
-    net, lines = generate(a.kinds, relu, tuple(int(x) for x in a.dma_at.split(",")), a.epi_start, a.ko, a.prio, a.stagger, a.young_prio)
+    net, lines = generate(a.kinds, relu, tuple(int(x) for x in a.dma_at.split(",")), a.epi_start, a.ko, a.prio, a.stagger, a.young_prio, a.mt)
+    T = a.tag
     with open(a.out, "w") as f:
-        f.write(f"// generated by nif_asm_gen.py --kinds {a.kinds} --relu {''.join('1' if r else '0' for r in relu)}: do not edit\n")
-        f.write(f"#define MI_NIF_ASM_KINDS \"{a.kinds}\"\n#define MI_NIF_ASM_RELU \"{''.join('1' if r else '0' for r in relu)}\"\n")
-        f.write(f"#define MI_NIF_ASM_CHUNKS {len(net.chunks)}\n#define MI_NIF_ASM_BIAS_FLOATS {net.bias_floats}\n")
-        f.write("#define MI_NIF_ASM_CLOBBERS " + ", ".join(f'"v{k}"' for k in range(LAST_VGPR + 1)) + ", " +
-                ", ".join(f'"s{k}"' for k in range(40, 48)) + ', "vcc", "scc", "memory"\n')
-        f.write("#define MI_NIF_ASM_BODY \\\n")
+        f.write(f"// generated by nif_asm_gen.py --kinds {a.kinds} --relu {''.join('1' if r else '0' for r in relu)} --waves {NW} --mt {a.mt}: do not edit\n")
+        f.write(f"#define MI_NIF_ASM_KINDS{T} \"{a.kinds}\"\n#define MI_NIF_ASM_RELU{T} \"{''.join('1' if r else '0' for r in relu)}\"\n")
+        f.write(f"#define MI_NIF_ASM_CHUNKS{T} {len(net.chunks)}\n#define MI_NIF_ASM_BIAS_FLOATS{T} {net.bias_floats}\n#define MI_NIF_ASM_WAVES{T} {NW}\n#define MI_NIF_ASM_MT{T} {a.mt}\n")
+        f.write(f"#define MI_NIF_ASM_CLOBBERS{T} " + ", ".join(generate.layout.clobbers()) + "\n")
+        f.write(f"#define MI_NIF_ASM_BODY{T} \\\n")
         for ln in lines:
             f.write(f'  "{ln}\\n\\t" \\\n')
         f.write('  ""\n')

@@ -603,7 +603,7 @@ __device__ __forceinline__ uint32_t nif_uniform(uint32_t x) { return (uint32_t)_
 
 inline bool nif_asm_covers(const NifRegsDevice& nr);                                                               // nif_asm_kernel.hpp
 inline void nif_asm_launch(const NifRegsDevice& nr, const float* u, const float* v, const uint32_t* idx, const uint32_t* countPtr,
-                           uint32_t numRows, float* bgrOut, mi_trace_result* rays, hipStream_t stream, bool scatter, uint32_t numCUs, unsigned long long* clockOut);
+                           uint32_t numRows, float* bgrOut, mi_trace_result* rays, hipStream_t stream, bool scatter, uint32_t numCUs, unsigned long long* clockOut, uint32_t which);
 inline void nif_regs_launch(const NifRegsDevice& nr, const float* u, const float* v, const uint32_t* idx, const uint32_t* countPtr,
                             uint32_t numRows, float* bgrOut, mi_trace_result* rays, hipStream_t stream, bool scatter, uint32_t numCUs, uint32_t variant);      // nif_regs_kernel.hpp
 
@@ -619,7 +619,8 @@ inline void nif_launch_mlp(const NifDevice& nif, const float* u, const float* v,
   // shape 7 ("auto", the default) = K3a, the hand-scheduled register-resident kernel (nif_asm_kernel.hpp), for the network shape its
   // body was generated for (the reference's 6 x 320 with the features re-concatenated in the middle), nif_mlp_kernel's w6 for every
   // other network; 6 ("a8") asks for K3a by name (and still falls back when the network is not covered)
-  if ((shape == 6 || shape == 7) && nif_asm_covers(nif.regs)) { nif_asm_launch(nif.regs, u, v, idx, countPtr, numRows, bgrOut, rays, stream, scatter, numCUs, nif.d_clock); return; }
+  // 8 ("b4") = K3b: the same dataflow with four waves of 64 rays, one per SIMD (half the LDS bytes per MFMA)
+  if ((shape == 6 || shape == 7 || shape == 8) && nif_asm_covers(nif.regs)) { nif_asm_launch(nif.regs, u, v, idx, countPtr, numRows, bgrOut, rays, stream, scatter, numCUs, nif.d_clock, shape == 8 ? 4u : 2u); return; }
 #if MI_RAYLIB_VARIANTS
   if (shape >= 4 && shape <= 5 && nif.regs.ok) { nif_regs_launch(nif.regs, u, v, idx, countPtr, numRows, bgrOut, rays, stream, scatter, numCUs, shape == 5 ? 0u : 1u); return; }
 #endif

@@ -11,6 +11,9 @@
 #include "../nif_asm_kernel.hpp"
 
 using namespace mi;
+#ifndef MI_LAB_WHICH
+#define MI_LAB_WHICH 2u      // 2 = K3a's shape (8 waves x 2 ray tiles), 4 = K3b's (4 waves x 4): -DMI_LAB_WHICH=4u
+#endif
 
 struct Lab {
   NifDevice nif;
@@ -34,7 +37,7 @@ extern "C" double lab_time(void* h, int which, int reps, int numCUs) {
   Lab* L = (Lab*)h;
   if (which == 1 && !nif_asm_covers(L->nif.regs)) return -2.0;
   auto go = [&] {
-    if (which == 1) nif_asm_launch(L->nif.regs, L->u, L->v, nullptr, nullptr, L->n, L->out, nullptr, 0, false, (uint32_t)numCUs, nullptr);
+    if (which == 1) nif_asm_launch(L->nif.regs, L->u, L->v, nullptr, nullptr, L->n, L->out, nullptr, 0, false, (uint32_t)numCUs, nullptr, MI_LAB_WHICH);
     else nif_launch_mlp(L->nif, L->u, L->v, nullptr, nullptr, L->n, L->out, nullptr, 0, false, 0, (uint32_t)numCUs);
   };
   try {

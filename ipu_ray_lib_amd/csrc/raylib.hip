@@ -217,7 +217,7 @@ struct SceneOptions {
     }
     if (key == "nif_shape") {
       const std::string s(v);
-      if (s == "w6") nifShape = 0; else if (s == "t6") nifShape = 1; else if (s == "t4") nifShape = 2; else if (s == "a8") nifShape = 6; else if (s == "auto") nifShape = 7;
+      if (s == "w6") nifShape = 0; else if (s == "t6") nifShape = 1; else if (s == "t4") nifShape = 2; else if (s == "a8") nifShape = 6; else if (s == "auto") nifShape = 7; else if (s == "b4") nifShape = 8;
 #if MI_RAYLIB_VARIANTS
       else if (s == "r8") nifShape = 4; else if (s == "r8s") nifShape = 5;
 #else

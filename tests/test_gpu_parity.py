@@ -456,9 +456,10 @@ def _nif_weights(rng, hidden=320, embed=12, layers=6):
     return ks, bs, relu
 
 
-@pytest.mark.parametrize("shape", ["w6", "t4", "t6", "r8", "r8s", "a8", "a8 on 3 compute units"])
+@pytest.mark.parametrize("shape", ["w6", "t4", "t6", "r8", "r8s", "a8", "a8 on 3 compute units", "b4", "b4 on 3 compute units"])
 def test_nif_mlp_against_oracle(scenes, shape):
-    """(a8 names K3a, the hand-scheduled register-resident kernel of nif_asm_kernel.hpp, in the shipped library; on a grid for 3
+    """(a8 / b4 name K3a / K3b, the hand-scheduled register-resident kernel of nif_asm_kernel.hpp in its two workgroup shapes - eight
+    waves of 32 rays, four waves of 64 rays with one activation set in the accumulator file -, in the shipped library; on a grid for 3
     compute units every workgroup runs fourteen passes, so the weight ring wraps from pass to pass in all three phases)
     (both MLP kernels: w6 (the default) / t4 / t6 are the workgroup shapes of nif_mlp_kernel; r8 / r8s name K3r, the
     register-resident kernel of nif_regs_kernel.hpp - measured slower, kept selectable - with its waves in lock-step / staggered)

@@ -47,7 +47,7 @@ def main():
     ms = e0.elapsed_time(e1) / reps
     flops_per_ray = 2 * sum(k * c for k, c in dims)
     tf = n * flops_per_ray / (ms * 1e-3) / 1e12
-    print(json.dumps({"kernel": "nif_regs_kernel" if a.shape in ("r8", "r8s") else "nif_asm_kernel" if a.shape in ("a8", "auto") else "nif_mlp_kernel", "shape": a.shape, "rays": n, "ms": ms, "rays_per_s": n / (ms * 1e-3), "flops_per_ray": flops_per_ray,
+    print(json.dumps({"kernel": "nif_regs_kernel" if a.shape in ("r8", "r8s") else "nif_asm_kernel" if a.shape in ("a8", "b4", "auto") else "nif_mlp_kernel", "shape": a.shape, "rays": n, "ms": ms, "rays_per_s": n / (ms * 1e-3), "flops_per_ray": flops_per_ray,
                       "tflops": tf, "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F16_PEAK_TFLOPS}}))
 
 

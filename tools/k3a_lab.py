@@ -33,7 +33,10 @@ def build(specs):
         defs = [w for w in words if w.startswith("-D")]      # (-DMI_K3A_KO=n: knock-outs in the C++ around the body)
         subprocess.run([sys.executable, str(ROOT / "ipu_ray_lib_amd" / "csrc" / "nif_asm_gen.py"), str(inc)] + [w for w in words if not w.startswith("-D")], check=True)
         (OUT / f"lib_{name}.args").write_text(args)
-        cmd = ["/opt/rocm/bin/hipcc", *FLAGS, *defs, f'-DMI_NIF_ASM_BODY_INC="{inc}"', "-I", str(ROOT / "include"), "-o", str(OUT / f"lib_{name}.so"),
+        which_b = "--mt" in words and words[words.index("--mt") + 1] == "4"      # K3b: four waves x four ray tiles (use with --waves,4,--tag,_B)
+        other = ROOT / "ipu_ray_lib_amd" / "csrc" / ("nif_asm_body.inc" if which_b else "nif_asm_body_b.inc")
+        body_defs = [f'-DMI_NIF_ASM_BODY_B_INC="{inc}"', f'-DMI_NIF_ASM_BODY_INC="{other}"', "-DMI_LAB_WHICH=4u"] if which_b else [f'-DMI_NIF_ASM_BODY_INC="{inc}"', f'-DMI_NIF_ASM_BODY_B_INC="{other}"']
+        cmd = ["/opt/rocm/bin/hipcc", *FLAGS, *defs, *body_defs, "-I", str(ROOT / "include"), "-o", str(OUT / f"lib_{name}.so"),
                str(ROOT / "ipu_ray_lib_amd" / "csrc" / "probe" / "k3a_lab.hip")]
         procs.append(subprocess.Popen(cmd))
         if len(procs) >= 4:
