@@ -230,7 +230,7 @@ int mi_scene_set_ray_batch(mi_scene* scene, size_t rays_per_batch);
  *   "tiles"         0 | 1           walk row-structured streams in 8x8 pixel tiles
  *   "seg_budget_kb" N >= 1          partial-sum buffer budget per launch
  *   "nif_spl"       0..128          NIF samples per launch (0 = default)
- *   "nif_shape"     auto | a8 | w6 | t6 | t4    which NIF MLP kernel runs: auto (default) = a8 where its generated body covers the network
+ *   "nif_shape"     auto | a8 | b4 | w6 | t6 | t4    which NIF MLP kernel runs (b4 = K3a's dataflow with four waves of 64 rays: 3 % slower): auto (default) = a8 where its generated body covers the network
  *                                   (the reference's 6 x 320 shape), w6 otherwise; a8 = K3a, the hand-scheduled register-resident kernel
  *                                   (csrc/nif_asm_kernel.hpp); w6 | t6 | t4 = workgroup shapes of nif_mlp_kernel; the variants build also takes
  *                                   r8 | r8s = K3r (csrc/nif_regs_kernel.hpp: measured slower; refused by the shipped library)

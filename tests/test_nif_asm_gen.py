@@ -1,5 +1,6 @@
-"""Replay of K3a's generated instruction stream (csrc/nif_asm_gen.py; no GPU): every statement of the hand-scheduled dense stack is
-checked against what the dataflow needs, the way tests/test_asm_pipeline_audit.py checks K3's hand-counted waits.
+"""Replay of K3a's (and K3b's: the four-wave shape) generated instruction stream (csrc/nif_asm_gen.py; no GPU): every statement of the
+hand-scheduled dense stack is checked against what the dataflow needs, the way tests/test_asm_pipeline_audit.py checks K3's hand-counted
+waits.
 
 The replay keeps, per register, WHAT it holds (which weight fragment, which bias tile, which activation) and whether the LDS read
 that fills it has been retired by a counted wait, and walks the text:
@@ -26,16 +27,23 @@ import nif_asm_gen as gen      # noqa: E402
 
 
 def regs_of(tok):
-    m = re.match(r"v\[(\d+):(\d+)\]$", tok)
+    """'v[8:11]' / 'a[0:3]' / 'v7' -> [('v', 8), ...]; None for anything else (operands, constants)."""
+    m = re.match(r"([va])\[(\d+):(\d+)\]$", tok)
     if m:
-        return list(range(int(m.group(1)), int(m.group(2)) + 1))
-    m = re.match(r"v(\d+)$", tok)
-    return [int(m.group(1))] if m else None
+        return [(m.group(1), k) for k in range(int(m.group(2)), int(m.group(3)) + 1)]
+    m = re.match(r"([va])(\d+)$", tok)
+    return [(m.group(1), int(m.group(2)))] if m else None
 
 
-def replay(kinds, relu, **kw):
-    net, lines = gen.generate(kinds, relu, **kw)
+def replay(kinds, relu, mt=2, nw=8, **kw):
+    gen.NW = nw
+    try:
+        net, lines = gen.generate(kinds, relu, mt=mt, **kw)
+    finally:
+        gen.NW = 8
+    L = gen.Lay(mt, nw)
     HT, D = gen.HT, gen.D
+    pieces_of = lambda cnt: len([p for p in range(40) if nw * p < cnt])      # noqa: E731
     # what the stream holds: consumed fragments in order
     expect = []
     for c, (first, cnt) in enumerate(net.chunks):
@@ -45,24 +53,30 @@ def replay(kinds, relu, **kw):
                 expect.append((c, q) + f)
     holds = {}                 # register -> content
     pending = []               # outstanding LDS reads: (dest registers, content)
-    cur_chunk_read = None      # chunk whose slot v216 points at
+    cur_chunk_read = None      # chunk whose slot the address register points at
     entered = set()            # chunks whose entry (vmcnt(0) + barrier) this wave has passed
     dma = {}                   # chunk (absolute, may be nchunks = next pass's 0) -> pieces issued
     n_mfma = 0
-    acc_state = {}             # accumulator base -> dict(l, j, tt, m, done k-steps, last mfma index)
+    acc_state = {}             # accumulator base register -> dict(l, j, tt, m, done k-steps, last mfma index)
+    out_bias = {}              # K3b, final layer: output operand -> bias offset loaded into it
     act = {}                   # activation register -> (layer, j, m, idx, relu applied)
-    step_i = 0                 # index into expect (each consumed twice: m = 0, 1)
+    tmp = {}                   # K3b: temporary -> (layer, j, m, idx, relu applied) on its way to the accumulator file
+    step_i = 0                 # index into expect (each consumed mt times)
     m_next = 0
     drained = barrier_after_drain = False
     last_m0 = None
     nchunks = len(net.chunks)
+    VA = ("v", L.vaddr())
+    acc_lo, acc_hi = gen.ACC, gen.ACC + 2 * L.acc_stride
 
     def in_flight(regs):
         return [p for p in pending if set(p[0]) & set(regs)]
 
+    def act_base(which, ks, m):
+        f, base = L.act(which, ks, m)
+        return [(f, base + k) for k in range(4)]
+
     for ln, t in enumerate(lines):
-        if t.startswith("; ---- chunk"):
-            continue
         if t.startswith(";"):
             continue
         op, _, rest = t.partition(" ")
@@ -74,7 +88,7 @@ def replay(kinds, relu, **kw):
                 assert n <= 15
                 while len(pending) > n:
                     dest, content = pending.pop(0)
-                    for k, r in enumerate(dest):
+                    for r in dest:
                         holds[r] = content
             if "vmcnt(0)" in t:
                 drained = True; barrier_after_drain = False
@@ -83,7 +97,7 @@ def replay(kinds, relu, **kw):
             assert drained, f"line {ln}: a barrier without the wave's pieces waited for"
             barrier_after_drain = True
             continue
-        if op == "v_add_u32" and args[0] == f"v{gen.VADDR}":
+        if op == "v_add_u32" and regs_of(args[0]) == [VA]:
             # the wave turns to the next chunk's slot: behind vmcnt(0) + barrier
             assert barrier_after_drain, f"line {ln}: chunk entry without wait + barrier"
             cur_chunk_read = 0 if cur_chunk_read is None else cur_chunk_read + 1
@@ -91,21 +105,33 @@ def replay(kinds, relu, **kw):
             # every piece of this chunk must have been issued (by this wave) before its entry - except the first chunk of the pass,
             # which the previous pass (or the kernel's prologue) fetched
             if cur_chunk_read > 0:
-                want = len([p for p in range(5) if 8 * p < net.chunks[cur_chunk_read][1]])
+                want = pieces_of(net.chunks[cur_chunk_read][1])
                 assert dma.get(cur_chunk_read, 0) == want, (cur_chunk_read, dma.get(cur_chunk_read), want)
             drained = False
             continue
         if op == "ds_read_b128":
-            dest = regs_of(args[0])
-            assert not in_flight(dest), f"line {ln}: read into registers with a read in flight"
             off = int(re.search(r"offset:(\d+)", t).group(1))
-            if args[1].startswith(f"v{gen.VADDR}"):
+            addr = args[1].split()[0]
+            if regs_of(addr) == [VA]:
+                dest = regs_of(args[0])
+                assert not in_flight(dest), f"line {ln}: read into registers with a read in flight"
                 assert cur_chunk_read in entered
                 content = ("frag", cur_chunk_read, off // 1024)
                 assert off // 1024 < net.chunks[cur_chunk_read][1]
             else:
-                assert args[1].startswith("%[biasv]")
+                assert addr == "%[biasv]"
                 content = ("bias", off)
+                dest = regs_of(args[0])
+                if dest is None:                       # K3b: the final layer's bias straight into an output operand
+                    assert re.match(r"%\[o\d\]$", args[0])
+                    dest = [("o", int(args[0][3]))]
+                else:
+                    assert not in_flight(dest), f"line {ln}: read into registers with a read in flight"
+                    if mt != 2:                        # K3b: into an accumulator, whose previous pair must have been converted
+                        assert acc_lo <= dest[0][1] < acc_hi and dest[0][0] == "v"
+                        st = acc_state.get(dest[0])
+                        assert st is None or st.get("converted"), f"line {ln}: bias loaded into an accumulator that is not converted yet"
+                        acc_state[dest[0]] = dict(bias=off, steps=0, converted=False)
             pending.append((dest, content))
             assert len(pending) <= 15
             continue
@@ -116,8 +142,8 @@ def replay(kinds, relu, **kw):
             # which chunk: from the source offset of the s_add in front of it
             src = int(re.search(r", (\d+)$", lines[ln - 4]).group(1)) // 1024
             tgt = [c for c, (first, cnt) in enumerate(net.chunks) if first <= src < first + cnt][0]
-            p = (src - net.chunks[tgt][0]) // 8
-            assert (src - net.chunks[tgt][0]) % 8 == 0 and last_m0 == 8192 * p
+            p = (src - net.chunks[tgt][0]) // nw
+            assert (src - net.chunks[tgt][0]) % nw == 0 and last_m0 == nw * 1024 * p
             absolute = tgt if tgt > (cur_chunk_read or 0) else tgt + nchunks
             assert absolute == cur_chunk_read + 1, f"line {ln}: a piece of chunk {absolute} issued while chunk {cur_chunk_read} is being read"
             assert dma.get(absolute, 0) == p, "pieces in order, each once"
@@ -130,53 +156,77 @@ def replay(kinds, relu, **kw):
             kind = net.kinds[l]
             last = kind in "LM"
             ra = regs_of(a_)
+            assert ra == [(L.ring(step_i % D)[0], L.ring(step_i % D)[1] + k) for k in range(4)]
             assert not in_flight(ra), f"line {ln}: MFMA reads a fragment that has not landed"
             assert all(holds.get(r) == ("frag", c, q) for r in ra), f"line {ln}: A operand holds {holds.get(ra[0])}, wanted fragment {(c, q)}"
             act_steps = 0 if kind == "F" else HT
             if ks < act_steps:
                 rb = regs_of(b_)
-                base = (gen.SETA if l % 2 == 1 else gen.SETB) + 8 * ks + 4 * m
-                assert rb == list(range(base, base + 4)), (ln, b_, base)
+                assert rb == act_base(0 if l % 2 == 1 else 1, ks, m), (ln, b_)
                 for k, r in enumerate(rb):
-                    assert act.get(r) == (l - 1, ks, m, k, bool(relu[l - 1])), f"line {ln}: B register v{r} holds {act.get(r)}"
+                    assert act.get(r) == (l - 1, ks, m, k, bool(relu[l - 1])), f"line {ln}: B register {r} holds {act.get(r)}"
             else:
                 assert b_ == f"%[f{ks - act_steps}{m}]", (ln, b_)
+            tile = 0 if last else 2 * j + tt
+            want_bias = ("bias", 4 * net.bias_base[l] + 64 * tile)
             if last:
                 assert d_ == f"%[o{m}]"
+                rd_ = [("o", m)]
             else:
                 rd_ = regs_of(d_)
-                assert gen.ACC <= rd_[0] < gen.ACC + 32
-            if ks == 0:
-                rc = regs_of(c_)
-                assert not in_flight(rc)
-                tile = 0 if last else 2 * j + tt
-                assert all(holds.get(r) == ("bias", 4 * net.bias_base[l] + 64 * tile) for r in rc), f"line {ln}: C operand {holds.get(rc[0])}"
-                if not last:
-                    st = acc_state.get(rd_[0])
-                    assert st is None or st.get("converted"), f"line {ln}: accumulator rewritten before its epilogue"
-                    acc_state[rd_[0]] = dict(l=l, j=j, tt=tt, m=m, steps=1, last=n_mfma, converted=False)
+                assert rd_[0][0] == "v" and acc_lo <= rd_[0][1] < acc_hi
+            if mt == 2:
+                if ks == 0:
+                    rc = regs_of(c_)
+                    assert not in_flight(rc)
+                    assert all(holds.get(r) == want_bias for r in rc), f"line {ln}: C operand {holds.get(rc[0])}"
+                    if not last:
+                        st = acc_state.get(rd_[0])
+                        assert st is None or st.get("converted"), f"line {ln}: accumulator rewritten before its epilogue"
+                        acc_state[rd_[0]] = dict(l=l, j=j, tt=tt, m=m, steps=1, last=n_mfma, converted=False)
+                else:
+                    assert c_ == d_
+                    if not last:
+                        st = acc_state[rd_[0]]
+                        assert (st["l"], st["j"], st["tt"], st["m"]) == (l, j, tt, m) and st["steps"] == ks
+                        st["steps"] += 1; st["last"] = n_mfma
             else:
+                # K3b: every MFMA accumulates; the first one of a pair finds the bias in its accumulator, landed
                 assert c_ == d_
-                if not last:
+                if ks == 0:
+                    assert not in_flight(rd_), f"line {ln}: the bias of the accumulator has not landed"
+                    assert all(holds.get(r) == want_bias for r in rd_), f"line {ln}: accumulator holds {holds.get(rd_[0])}, wanted {want_bias}"
+                    for r in rd_:
+                        holds[r] = None
+                    if not last:
+                        st = acc_state[rd_[0]]
+                        assert st["steps"] == 0
+                        st.update(l=l, j=j, tt=tt, m=m, steps=1, last=n_mfma)
+                elif not last:
                     st = acc_state[rd_[0]]
                     assert (st["l"], st["j"], st["tt"], st["m"]) == (l, j, tt, m) and st["steps"] == ks
                     st["steps"] += 1; st["last"] = n_mfma
             n_mfma += 1
-            m_next ^= 1
+            m_next = (m_next + 1) % mt
             if m_next == 0:
                 step_i += 1
             continue
         if op == "v_cvt_pk_f16_f32":
             dst = regs_of(args[0])[0]; a0 = regs_of(args[1])[0]; a1 = regs_of(args[2])[0]
-            assert a1 == a0 + 1
-            base = gen.ACC + ((a0 - gen.ACC) // 4) * 4
+            assert a1 == (a0[0], a0[1] + 1) and a0[0] == "v"
+            base = ("v", gen.ACC + ((a0[1] - gen.ACC) // 4) * 4)
             st = acc_state[base]
             assert st["steps"] == net.ks[st["l"]], f"line {ln}: convert of an unfinished accumulator"
             assert n_mfma - st["last"] > 4, f"line {ln}: convert {n_mfma - st['last']} MFMAs behind the accumulator's last write"
-            half = (a0 - base) // 2
-            want_dst = (gen.SETA if st["l"] % 2 == 0 else gen.SETB) + 8 * st["j"] + 4 * st["m"] + 2 * st["tt"] + half
-            assert dst == want_dst, (ln, dst, want_dst)
-            act[dst] = (st["l"], st["j"], st["m"], 2 * st["tt"] + half, False)
+            half = (a0[1] - base[1]) // 2
+            idx = 2 * st["tt"] + half
+            final = act_base(0 if st["l"] % 2 == 0 else 1, st["j"], st["m"])[idx]
+            if final[0] == "v":
+                assert dst == final, (ln, dst, final)
+                act[dst] = (st["l"], st["j"], st["m"], idx, False)
+            else:
+                assert dst[0] == "v" and 224 <= dst[1] < 232, f"line {ln}: a convert for the accumulator-file set goes through a temporary"
+                tmp[dst] = (st["l"], st["j"], st["m"], idx, False)
             st.setdefault("cv", set()).add(half)
             if len(st["cv"]) == 2:
                 st["converted"] = True
@@ -184,17 +234,25 @@ def replay(kinds, relu, **kw):
         if op == "v_pk_max_f16":
             dst = regs_of(args[0])[0]
             assert regs_of(args[1])[0] == dst and args[2] == "0"
-            l0, j0, m0_, k0, r0 = act[dst]
+            where = act if dst in act and not (224 <= dst[1] < 232 and dst[0] == "v" and mt != 2) else tmp
+            l0, j0, m0_, k0, r0 = where[dst]
             assert relu[l0] and not r0
-            act[dst] = (l0, j0, m0_, k0, True)
+            where[dst] = (l0, j0, m0_, k0, True)
+            continue
+        if op == "v_accvgpr_write_b32":
+            dst = regs_of(args[0])[0]; src = regs_of(args[1])[0]
+            l0, j0, m0_, k0, r0 = tmp.pop(src)
+            assert r0 == bool(relu[l0]), f"line {ln}: moved before its ReLU"
+            assert dst == act_base(1, j0, m0_)[k0] and l0 % 2 == 1
+            act[dst] = (l0, j0, m0_, k0, r0)
             continue
         if op in ("s_add_u32", "s_addc_u32", "s_cmp_lt_u32", "s_cselect_b32", "s_mov_b32", "s_sub_u32", "s_nop"):
             continue
         raise AssertionError(f"line {ln}: unexpected instruction {t}")
-    assert step_i == len(expect) and not pending
-    assert n_mfma == 2 * len(expect)
+    assert step_i == len(expect) and not pending and not tmp
+    assert n_mfma == mt * len(expect)
     # the pieces of the next pass's chunk 0 went out in this pass's last chunk
-    assert dma.get(nchunks) == 5
+    assert dma.get(nchunks) == pieces_of(40)
     return n_mfma, len(lines)
 
 
@@ -206,6 +264,16 @@ def test_generated_body_replays(kinds):
     assert n_mfma == 2 * sum(per_tile[k] for k in kinds)
 
 
+@pytest.mark.parametrize("kinds", ["FPPCPPL", "FPL", "FCPM"])
+def test_generated_body_of_the_four_wave_shape_replays(kinds):
+    """K3b: four waves of 64 rays, one activation set, the fragment ring in the accumulator file, the bias loaded into the accumulators."""
+    relu = [True] * (len(kinds) - 1) + [False]
+    n_mfma, n_lines = replay(kinds, relu, mt=4, nw=4)
+    per_tile = {"F": 40, "P": 200, "C": 240, "L": 10, "M": 12}
+    assert n_mfma == 4 * sum(per_tile[k] for k in kinds)
+
+
 def test_generated_body_other_placements_replay():
     relu = [True, True, False, True, True, True, False]
     replay("FPPCPPL", relu, dma_at=(2, 5, 9, 14, 20), epi_start=6)
+    replay("FPPCPPL", relu, mt=4, nw=4, epi_start=6)
