@@ -212,6 +212,8 @@ def campaign(budget=240.0, seed=1, scale=1, max_cases=None):
         # sources otherwise: both are under the campaign
         use_variants = kernel not in ("0", "1") or waves != "6" or spec == 1 or merge == 0
         dev = irl.IpuScene(d, variants=use_variants).set_option("kernel", kernel).set_option("waves", waves).set_option("spec", spec).set_option("double_fallback", df)
+        # (round 5's two builds of the default form for scenes without vertex normals: drawn off one case in four each)
+        dev.set_option("lean_hit", int(rng.integers(0, 4) != 0)).set_option("leaf_rot", int(rng.integers(0, 4) != 0))
         if use_variants:
             dev.set_option("merge", merge)
         got = s.init_ray_stream()
