@@ -204,6 +204,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
   uint32_t casts = 0, paths = 0;       // wave-uniform: counted per turn from the turn's ballots, so they live in scalar registers
   // STATS only: per-wave phase executions and the lanes that were active in them (wave-uniform values)
   uint32_t itN = 0, itL = 0, itS = 0, itG = 0, lnN = 0, lnL = 0, lnS = 0, lnG = 0;
+  uint32_t itQ = 0, lnQ = 0;      // (instrumented build) primitive-test turns that hold a sphere or disc lane, and those lanes
   unsigned long long tTrav = 0, tShade = 0, tGen = 0, tLoop0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;   // STATS: shader cycles per phase
 
   // Slot mode: the escaped paths of a SHADE turn append their slots to the list the MLP consumes (ex.index, ex.count), with
@@ -501,6 +502,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
             float t, b0 = 0.f, b1 = 0.f, b2 = 0.f;
             bool cand;
             const uint32_t kind = leaf_kind(L);
+            if (STATS) { const unsigned long long qm = __ballot(kind != LEAF_TRI); itQ += qm ? 1u : 0u; lnQ += (uint32_t)__popcll(qm); }
             if (kind == LEAF_TRI) {
               if constexpr (ROT) t = intersect_triangle<DF, true>(mk(L.f[0], L.f[1], L.f[2]), mk(L.f[3], L.f[4], L.f[5]), mk(L.f[6], L.f[7], L.f[8]), permute_kz(o, sh.kz), sh, b0, b1, b2);
               else
@@ -823,6 +825,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
   if (STATS && lane == 0) {
     atomicAdd(&sc.counters[4], (unsigned long long)itN); atomicAdd(&sc.counters[5], (unsigned long long)lnN);
     atomicAdd(&sc.counters[6], (unsigned long long)itL); atomicAdd(&sc.counters[7], (unsigned long long)lnL);
+    atomicAdd(&sc.counters[16], (unsigned long long)itQ); atomicAdd(&sc.counters[17], (unsigned long long)lnQ);      // (read through mi_get_pool_stats: slots 0 and 1; the pool kernel is not this kernel)
     atomicAdd(&sc.counters[8], (unsigned long long)itS); atomicAdd(&sc.counters[9], (unsigned long long)lnS);
     atomicAdd(&sc.counters[10], (unsigned long long)itG); atomicAdd(&sc.counters[11], (unsigned long long)lnG);
     atomicAdd(&sc.counters[12], tTrav); atomicAdd(&sc.counters[13], tShade); atomicAdd(&sc.counters[14], tGen);

@@ -37,8 +37,11 @@ def main():
     cy = p["cycles"]
     tot = float(cy["total"]) or 1.0
     print("  cycles: traverse %.3f  shade %.3f  gen %.3f" % (cy["traverse"] / tot, cy["shade"] / tot, cy["gen"] / tot))
+    q = dev.pool_stats()      # (the instrumented default kernel leaves two counters there: primitive-test turns that hold a sphere or disc lane, and those lanes)
+    if p["leaf"]["iters"]:
+        print(f"  primitive-test turns with a sphere / disc lane: {q['loops'] / p['leaf']['iters']:.3f} of them, {q['refill_turns'] / max(q['loops'], 1):.2f} such lanes per such turn")
     ps = dev.pool_stats()
-    if ps["loops"]:
+    if ps["bursts"]:      # (only the path-pool kernel leaves these)
         wc = c["casts"] / 64.0
         print("  pool: per 64 casts: loops %.2f  refill turns %.2f (%.1f lanes each)  bursts %.2f (%.1f lanes at start)  idle %.2f  lost claims %.3f; refill cycles %.3f" % (
             ps["loops"] / wc, ps["refill_turns"] / wc, ps["refill_lanes"] / max(ps["refill_turns"], 1), ps["bursts"] / wc,
