@@ -89,9 +89,14 @@ def to_device(torch, irl, host_rays):
     return torch.from_numpy(host_rays.view(np.uint8).reshape(host_rays.size, irl.TRACE_RESULT.itemsize).copy()).cuda()
 
 
-def time_launches(torch, fn, reps, stream):
-    """Average duration of `fn` (enqueues on `stream`) over `reps` calls, HIP events on that stream."""
+def time_launches(torch, fn, reps, stream, ahead=0):
+    """Average duration of `fn` (enqueues on `stream`) over `reps` calls, HIP events on that stream. `ahead` more calls run before
+    the first event WITHOUT a wait in between (millisecond launches: a device that went idle behind a synchronize takes about a
+    millisecond to get its clocks back, which a 20 x 1.5 ms region would book as 4 % of every launch - tools/bench_nif.py --reps
+    5 / 20 / 100 / 400 without them: 1.76 / 1.61 / 1.55 / 1.54 ms on one box; launches in a render follow each other like these)."""
     fn(); torch.cuda.synchronize()
+    for _ in range(ahead):
+        fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
     for _ in range(reps):
@@ -578,10 +583,10 @@ def main():
         u = torch.rand(nr, device="cuda"); v = torch.rand(nr, device="cuda"); bgr = torch.empty(nr, 3, device="cuda")
         # the default kernel for this network (nif_shape auto: K3a, the hand-scheduled register-resident kernel) - 20 launches, the
         # clock of the last one from the kernel's own counter reads (mi_get_nif_clock) - and nif_mlp_kernel (w6) beside it
-        ms = time_launches(torch, lambda: ns.nif_infer_device(u.data_ptr(), v.data_ptr(), bgr.data_ptr(), nr, stream.cuda_stream), 20, stream)
+        ms = time_launches(torch, lambda: ns.nif_infer_device(u.data_ptr(), v.data_ptr(), bgr.data_ptr(), nr, stream.cuda_stream), 20, stream, ahead=3)
         ghz = ns.nif_clock_ghz()
         ns.set_option("nif_shape", "w6")
-        ms_w6 = time_launches(torch, lambda: ns.nif_infer_device(u.data_ptr(), v.data_ptr(), bgr.data_ptr(), nr, stream.cuda_stream), 20, stream)
+        ms_w6 = time_launches(torch, lambda: ns.nif_infer_device(u.data_ptr(), v.data_ptr(), bgr.data_ptr(), nr, stream.cuda_stream), 20, stream, ahead=3)
         ns.set_option("nif_shape", "auto")
         flops_per_ray = 2 * sum(k * c for k, c in dims)
         tf = nr * flops_per_ray / (ms * 1e-3) / 1e12

@@ -123,11 +123,10 @@ class Lay:
     K3a (MT = 2 ray tiles per wave, 8 waves = two per SIMD, 256 registers): everything in architectural registers (header).
     K3b (MT = 4, 4 waves = one per SIMD, 512 registers = 256 architectural + 256 accumulator-file): activation set A in v[0:159], set
     B in a[0:159] (an MFMA takes its B operand from either file; a layer that writes set B converts into temporaries and moves them
-    with v_accvgpr_write), accumulators v[160:223] (two buffers of [tile][ray tile][4]), eight temporaries v[224:231], the chunk address
-    v232, the fragment ring a[160:175] (ds_read_b128 fills accumulator-file registers directly; an MFMA reads its A operand from
-    them). An MFMA's C and D operands share one file, so there is no bias register: a pair's accumulators are LOADED with the bias
-    (ds_read_b128 into the accumulator, one per tile and ray tile, issued as soon as the buffer's previous pair has been converted)
-    and every MFMA accumulates. Every A fragment read from LDS feeds FOUR MFMAs: half K3a's LDS bytes per MFMA."""
+    with v_accvgpr_write), accumulators v[160:223] (two buffers of [tile][ray tile][4]), four temporaries v[224:227], the pair's bias
+    v[228:235] (an MFMA's C and D operands share one register FILE, so the bias sits beside the accumulators), the chunk address v236,
+    the fragment ring a[160:175] (ds_read_b128 fills accumulator-file registers directly; an MFMA reads its A operand from them).
+    Every A fragment read from LDS feeds FOUR MFMAs: half K3a's LDS bytes per MFMA."""
 
     def __init__(self, mt, nw):
         self.mt, self.nw = mt, nw
@@ -136,7 +135,7 @@ class Lay:
             self.last_v, self.last_a = LAST_VGPR, -1
         else:
             self.acc_stride = 32
-            self.last_v, self.last_a = 232, 175
+            self.last_v, self.last_a = 236, 175
 
     def reg(self, f, base, n=4):
         return f"{f}[{base}:{base + n - 1}]" if n > 1 else f"{f}{base}"
@@ -153,16 +152,17 @@ class Lay:
         return ("v", RING + 4 * i) if self.mt == 2 else ("a", 160 + 4 * i)
 
     def bias(self, tt):
-        return ("v", BIAS + 4 * tt) if self.mt == 2 else ("a", 176 + 4 * tt)
+        return ("v", BIAS + 4 * tt) if self.mt == 2 else ("v", 228 + 4 * tt)      # (K3b: v[228:235]; an MFMA's C and D share a FILE, not a register)
 
     def vaddr(self):
-        return VADDR if self.mt == 2 else 232
+        return VADDR if self.mt == 2 else 236
 
     def tmp(self, k):
         return 224 + k
 
     def clobbers(self):
-        return ([f'"v{k}"' for k in range(self.last_v + 1)] + [f'"a{k}"' for k in range(self.last_a + 1)] +
+        out_regs = set() if self.mt == 2 else set(range(ACC, ACC + 16))      # (K3b: the outputs are tied to v[160:175], so they are operands, not clobbers)
+        return ([f'"v{k}"' for k in range(self.last_v + 1) if k not in out_regs] + [f'"a{k}"' for k in range(self.last_a + 1)] +
                 [f'"s{k}"' for k in range(40, 48)] + ['"vcc"', '"scc"', '"memory"'])
 
 
@@ -256,7 +256,7 @@ def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4, ko=0, prio=0, 
         for m in range(mt):
             f, dst = L.act(out_which(l), j, m)
             # (an accumulator-file destination: convert into temporaries, ReLU there, move)
-            tgt = [dst + k for k in range(4)] if f == "v" else [L.tmp(4 * (m % 2) + k) for k in range(4)]
+            tgt = [dst + k for k in range(4)] if f == "v" else [L.tmp(k) for k in range(4)]
             for t in (0, 1):
                 a = L.acc(buf, t, m)[1]
                 ins.append(f"v_cvt_pk_f16_f32 v{tgt[2 * t]}, v{a}, v{a + 1}")
@@ -291,10 +291,7 @@ def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4, ko=0, prio=0, 
     for si in range(min(D, nsteps)):
         assert steps[si]["c"] == 0
         ring_read(si)
-    if mt == 2:
-        bias_read(0, 0)
-    else:
-        bias_into_acc(0, 0)       # (pair 1's goes out behind pair 0's first k-step: lgkmcnt holds 15)
+    bias_read(0, 0)
 
     pending_epi = []            # VALU of the previous pair, dealt over the MFMA slots of the next pair from slot `epi_start` on
     pair_slot = 0               # MFMAs issued in the current pair
@@ -311,7 +308,7 @@ def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4, ko=0, prio=0, 
             pair_i += 1
         if not ko & 16:
             e.wait(("ring", si))
-        if ks == 0 and mt == 2:
+        if ks == 0:
             e.wait(("bias", l, j, tt))
         for m in range(mt):
             # B operand: the layer's input k-step, or a feature k-step
@@ -320,13 +317,16 @@ def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4, ko=0, prio=0, 
                 b = L.reg(*L.act(in_which(l), ks, m))
             else:
                 b = f"%[f{ks - act_steps}{m}]"
-            if last:
+            if last and mt == 2:
                 d_ = f"%[o{m}]"
+            elif last:
+                # K3b: the final layer accumulates in the accumulator buffer whose turn it is - the statement's outputs are TIED to those
+                # registers ("={v[160:163]}" ...: the register budget has no room for sixteen more operand registers)
+                assert buf == 0, "K3b's outputs are tied to accumulator buffer 0: the network must have an even number of pairs before its final layer"
+                d_ = L.reg(*L.acc(0, 0, m))
             else:
                 d_ = L.reg(*L.acc(buf, tt, m))
-            c_ = L.reg(*L.bias(tt)) if (ks == 0 and mt == 2) else d_
-            if ks == 0 and mt != 2:
-                e.wait(("biasacc", pair_i, tt, m))
+            c_ = L.reg(*L.bias(tt)) if ks == 0 else d_
             e.i(f"v_mfma_f32_16x16x32_f16 {d_}, {L.reg(*L.ring(si % D))}, {b}, {c_}")
             pair_slot += 1
             # fillers behind this MFMA
@@ -345,15 +345,9 @@ def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4, ko=0, prio=0, 
                 per = max(1, -(-len(pending_epi) // max(1, until - pair_slot + 1)))
                 for _ in range(min(per, len(pending_epi))):
                     e.i(pending_epi.pop(0))
-                if mt != 2 and not pending_epi and epi_buf is not None:
-                    # the buffer of the pair before this one is converted: the pair after this one loads its bias into it
-                    bias_into_acc(pair_i + 1, epi_buf)
-                    epi_buf = None
         # the NEXT pair's bias, as soon as this pair's first MFMAs (which take the bias as C) have issued
         is_pair_first_done = (ks == 0 and (tt == 1 or last))
-        if is_pair_first_done and mt != 2 and pair_i == 0:
-            bias_into_acc(1, 1)
-        if is_pair_first_done and mt == 2:
+        if is_pair_first_done:
             if not last and j + 1 < HT:
                 bias_read(l, j + 1)
             elif l + 1 < len(net.kinds) and not last:
@@ -381,9 +375,6 @@ def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4, ko=0, prio=0, 
         if not last and ks == KS - 1 and tt == 1:
             assert not pending_epi, "the previous pair's epilogue did not fit"
             pending_epi = [] if ko & 4 else epilogue(l, j, buf)
-            epi_buf = buf
-            if ko & 4 and mt != 2:
-                bias_into_acc(pair_i + 2, buf); epi_buf = None
             buf ^= 1
     assert not pending_epi
     # the slot of the next pass's chunk 0 (= where this pass's last entry pointed the fetches)

@@ -217,6 +217,10 @@ __device__ __forceinline__ void sincos_half_phase(float p, float& sn, float& cs)
 //   * the epilogue's ds_write_b64 (16 consecutive lanes = 16 rays, one column) is 2-way: 8 LDS cycles against the 6
 //     the instruction needs anyway (row-major with 8-bank row offsets it was 4-way: SQ_LDS_BANK_CONFLICT = 12 extra
 //     cycles per store).
+// An index-list entry that names no ray: the trace kernel reserves room in the escaped-slot list 2 048 entries at a time and marks the whole
+// 256-entry blocks a wave leaves unused (trace_wavefront.hpp kEnvHole). Every MLP kernel skips such rows (no coordinate load, no result);
+// K3a / K3b skip a pass of 256 holes altogether.
+constexpr uint32_t kNifHole = 0xFFFFFFFFu;
 constexpr uint32_t kNifGenerations = 64;      // workgroups launched per resident slot (nif_launch_mlp)
 
 template <uint32_t ROWS>
@@ -329,9 +333,11 @@ __device__ __forceinline__ void nif_dense_layers(const NifParams& P, uint32_t l0
                 if (P.logTonemap) o[c] = expf(o[c]);
               }
               const uint32_t row = row0 + r;
-              if (bgrOut) { const size_t dst = scatter ? (size_t)idx[row] : (size_t)row; bgrOut[3 * dst] = o[0]; bgrOut[3 * dst + 1] = o[1]; bgrOut[3 * dst + 2] = o[2]; }
+              const uint32_t src = idx ? idx[row] : row;
+              if (src == kNifHole) continue;          // (a hole of the escaped-slot list: no ray)
+              if (bgrOut) { const size_t dst = scatter ? (size_t)src : (size_t)row; bgrOut[3 * dst] = o[0]; bgrOut[3 * dst + 1] = o[1]; bgrOut[3 * dst + 2] = o[2]; }
               if (rays) {
-                mi_trace_result* res = rays + (idx ? idx[row] : row);
+                mi_trace_result* res = rays + src;
                 const mi_vec3 tp = res->h.throughput;
                 res->rgb.x += tp.x * o[2];          // BGR -> RGB (codelets/TraceCodelets.cpp:376)
                 res->rgb.y += tp.y * o[1];
@@ -547,7 +553,7 @@ __global__ void __launch_bounds__(256 * RG, (MT == 6 && RG == 1) ? 2 : 1) nif_ml
     for (uint32_t rr = gtid; rr < kGroupRows; rr += kGroupThreads) {
       const uint32_t r = rowBase + rr, row = row0 + r;
       float cu = 0.f, cv = 0.f;
-      if (row < total) { const uint32_t src = idx ? idx[row] : row; cu = u[src]; cv = v[src]; }
+      if (row < total) { const uint32_t src = idx ? idx[row] : row; if (src != kNifHole) { cu = u[src]; cv = v[src]; } }
       uvS[r] = cu; uvS[kNifRows + r] = cv;
     }
     __syncthreads();

@@ -250,9 +250,11 @@ __device__ __forceinline__ void nif_regs_final(NifRegsState& st, uint32_t lane16
         if (C1.logTonemap) o[c] = expf(o[c]);
       }
       const uint32_t row = row0 + r;
-      if (bgrOut) { const size_t dst = scatter ? (size_t)idx[row] : (size_t)row; bgrOut[3 * dst] = o[0]; bgrOut[3 * dst + 1] = o[1]; bgrOut[3 * dst + 2] = o[2]; }
+      const uint32_t src = idx ? idx[row] : row;
+      if (src == 0xFFFFFFFFu) continue;          // (kNifHole: a hole of the escaped-slot list)
+      if (bgrOut) { const size_t dst = scatter ? (size_t)src : (size_t)row; bgrOut[3 * dst] = o[0]; bgrOut[3 * dst + 1] = o[1]; bgrOut[3 * dst + 2] = o[2]; }
       if (rays) {
-        mi_trace_result* res = rays + (idx ? idx[row] : row);
+        mi_trace_result* res = rays + src;
         const mi_vec3 tp = res->h.throughput;
         res->rgb.x += tp.x * o[2];          // BGR -> RGB (codelets/TraceCodelets.cpp:376)
         res->rgb.y += tp.y * o[1];
@@ -316,7 +318,7 @@ __global__ void __launch_bounds__(64 * W) nif_regs_kernel(NifRegsCold C0, const 
       for (uint32_t m = 0; m < MT; ++m) {
         const uint32_t row = row0 + wave * (16u * MT) + 16u * m + (lane & 15u);
         float cu = 0.f, cv = 0.f;
-        if (row < total) { const uint32_t src = idxG ? idxG[row] : row; cu = uG[src]; cv = vG[src]; }
+        if (row < total) { const uint32_t src = idxG ? idxG[row] : row; if (src != 0xFFFFFFFFu) { cu = uG[src]; cv = vG[src]; } }
 #pragma unroll
         for (uint32_t c = 0; c < 2; ++c) {
           h8 fv;

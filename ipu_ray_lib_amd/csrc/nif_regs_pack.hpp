@@ -18,6 +18,7 @@ constexpr uint32_t kNifMaxLayers = 16;
 constexpr uint32_t kRegRows = 256;                             // rays per workgroup pass (8 waves x 2 ray tiles of 16)
 constexpr uint32_t kRegSlots = 3;                              // weight ring: slots of one chunk each
 constexpr uint32_t kRegFeatBytes = 32u * 1024u;                // the pass's Fourier features as B fragments: [wave][chunk][ray tile][lane x 16 B]
+constexpr uint32_t kRegPassCounters = 64u;                     // K3a / K3b: pass counters, one per launch in flight (nif_asm_kernel.hpp)
 constexpr uint32_t kRegMaxLdsBytes = 160u * 1024u;             // one workgroup per compute unit may take all of its LDS
 
 enum : uint32_t { RL_FIRST = 0, RL_PLAIN = 1, RL_CONCAT = 2, RL_LAST = 3, RL_LAST_CONCAT = 4 };
@@ -39,6 +40,8 @@ struct NifRegsDevice {
   NifRegsLayer* d_layers = nullptr;
   NifRegsCold* d_cold = nullptr;
   float* d_bias = nullptr;          // all layers' biases, 16 per output tile (zero padded)
+  uint32_t* d_passCtr = nullptr;    // kRegPassCounters zeroed words (K3a / K3b draw their passes from one per launch)
+  mutable uint32_t ctrNext = 0;
   std::vector<NifRegsLayer> layersHost;      // the layer table as uploaded (K3a's launch checks the layer sequence against the one its body was generated for)
   bool ok = false;
 
@@ -48,6 +51,8 @@ struct NifRegsDevice {
     if (d_layers) (void)hipFree(d_layers);
     if (d_cold) (void)hipFree(d_cold);
     if (d_bias) (void)hipFree(d_bias);
+    if (d_passCtr) (void)hipFree(d_passCtr);
+    d_passCtr = nullptr;
     d_stream = nullptr; d_chunks = nullptr; d_layers = nullptr; d_cold = nullptr; d_bias = nullptr; ok = false;
     layersHost.clear();
   }
@@ -134,6 +139,8 @@ struct NifRegsDevice {
     (void)hipMemcpy(d_stream, stream.data(), stream.size() * sizeof(_Float16), hipMemcpyHostToDevice);
     up(d_chunks, chunks); up(d_layers, layers); up(d_bias, bias);
     layersHost = layers;
+    if (hipMalloc(&d_passCtr, kRegPassCounters * sizeof(uint32_t)) != hipSuccess) throw std::runtime_error("NIF: hipMalloc failed");
+    (void)hipMemset(d_passCtr, 0, kRegPassCounters * sizeof(uint32_t));
     if (hipMalloc(&d_cold, sizeof(NifRegsCold)) != hipSuccess) throw std::runtime_error("NIF: hipMalloc failed");
     (void)hipMemcpy(d_cold, &P, sizeof P, hipMemcpyHostToDevice);
     ok = true;

@@ -118,6 +118,10 @@ struct SceneOptions {
   uint32_t nifTraceWgs = 0;        // "nif_trace_wgs": a NIF render's trace launch that runs beside the previous batch's MLP gets at most this many workgroups per
                                    // compute unit (0 = all that stay resident, the default: a cap of 1 paid 3 % while the trace launch queued behind its list
                                    // counter, and costs 0.7 % since it does not: profiles/r04_nif_overlap_ab.txt, r04_nif_trace_ab.txt)
+  uint32_t nifSplit = 0;           // "nif_split": compute units a NIF render's trace launches of batches 1.. get for themselves (CU-masked streams: the MLP's
+                                   // workgroups take every register of their unit, so a trace launch beside them otherwise only runs in their ramps and tails;
+                                   // the MLP is power-limited and loses less than the units it gives up: DESIGN.md §6). 0 = no partition
+  bool nifFirstTest = true;        // "nif_first_test": a NIF render's casts take their first box test in the turn that sets them up (trace_wavefront.hpp kFirstInSetup; 0 = in a NODE turn, for A/B)
   bool nifTiming = false;          // "nif_timing": HIP events round every MLP launch of a NIF render (mi_get_nif_timing)
   uint32_t nifGenerations = kNifGenerations;   // MI_RAYLIB_NIF_GENERATIONS / "nif_generations": MLP workgroups launched per resident slot (nif_launch_mlp; measurement knob)
   bool rootStart = true;           // MI_RAYLIB_NO_ROOT_START / "root_start": a cast whose origin lies strictly inside the root's box starts at node 1
@@ -196,6 +200,8 @@ struct SceneOptions {
     if (key == "root_start") return flag01(v, rootStart);
     if (key == "say_grid") return flag01(v, sayGrid);
     if (key == "nif_overlap") return flag01(v, nifOverlap);
+    if (key == "nif_first_test") return flag01(v, nifFirstTest);
+    if (key == "nif_split") { if (!number(v, 0, 1024, q)) return false; nifSplit = (uint32_t)q; return true; }
     if (key == "nif_trace_wgs") { if (!number(v, 0, 16, q)) return false; nifTraceWgs = (uint32_t)q; return true; }
     if (key == "coords") return flag01(v, coords);
     if (key == "lean_hit") return flag01(v, leanHit);
@@ -243,7 +249,7 @@ struct SceneOptions {
                                          {"MI_RAYLIB_NIF_SHAPE", "nif_shape"}, {"MI_RAYLIB_TUNE", "tune"},
                                          {"MI_RAYLIB_POOL_TUNE", "pool_tune"}, {"MI_RAYLIB_POOL_WAVES", "pool_waves"}, {"MI_RAYLIB_CUS", "cus"},
                                          {"MI_RAYLIB_NIF_OVERLAP", "nif_overlap"}, {"MI_RAYLIB_COORDS", "coords"},
-                                         {"MI_RAYLIB_NIF_TRACE_WGS", "nif_trace_wgs"}, {"MI_RAYLIB_NIF_GENERATIONS", "nif_generations"}};
+                                         {"MI_RAYLIB_NIF_TRACE_WGS", "nif_trace_wgs"}, {"MI_RAYLIB_NIF_SPLIT", "nif_split"}, {"MI_RAYLIB_NIF_GENERATIONS", "nif_generations"}};
     // (an unparsable environment value is ignored: the option keeps its default. The two options that select ARITHMETIC,
     // double_fallback and fast, are deliberately not in this list: a process that says "bit-exact" must not change tier
     // because of a variable somebody exported)
@@ -311,6 +317,11 @@ struct mi_scene {
     hipEvent_t traced = nullptr, done = nullptr; bool donePending = false;
   } nifSlots[2];
   hipStream_t nifAux = nullptr;
+  // option "nif_split": the same pair of streams with compute-unit masks (the first numCUs - x units / the last x; a mask's bit i is
+  // unit i / XCDs of XCD i % XCDs, so any multiple of the XCD count splits every XCD alike). splitUnits = x they were made for.
+  hipStream_t nifSplitMlp = nullptr, nifSplitTrace = nullptr;
+  uint32_t splitUnits = 0; bool splitRefused = false;
+  hipEvent_t splitFirst = nullptr;
   Rng* d_rng = nullptr; size_t scratchRays = 0;
   float* d_segTotal = nullptr;                                // sample-at-a-time NIF renders: sum of the finished segments, [n][3]
   uint32_t scratchSamples = 0;                                // samples per launch the slot buffers are sized for
@@ -327,11 +338,14 @@ struct mi_scene {
     // stream may be gone by now. hipFree below synchronises on its own account in this runtime; correctness does not rest on it.)
     for (LaunchSlot& l : slots) if (l.lastWork) (void)hipEventSynchronize(l.lastWork);
     if (nifAux) (void)hipStreamSynchronize(nifAux);
+    for (hipStream_t q : {nifSplitMlp, nifSplitTrace}) if (q) (void)hipStreamSynchronize(q);
     for (void* p : allocations) (void)hipFree(p);
     if (d_rng) (void)hipFree(d_rng);
     freeNifSlots();
     for (NifSlots& q : nifSlots) { if (q.count) (void)hipFree(q.count); if (q.traced) (void)hipEventDestroy(q.traced); if (q.done) (void)hipEventDestroy(q.done); }
     if (nifAux) (void)hipStreamDestroy(nifAux);
+    for (hipStream_t q : {nifSplitMlp, nifSplitTrace}) if (q) (void)hipStreamDestroy(q);
+    if (splitFirst) (void)hipEventDestroy(splitFirst);
     if (d_segTotal) (void)hipFree(d_segTotal);
     for (LaunchSlot& l : slots) { if (l.lastWork) (void)hipEventDestroy(l.lastWork); if (l.d_workCounter) (void)hipFree(l.d_workCounter); if (l.d_segPart) (void)hipFree(l.d_segPart); if (l.d_coords) (void)hipFree(l.d_coords); if (l.d_poolScratch) (void)hipFree(l.d_poolScratch); }
     for (int i = 0; i < 2; ++i) { if (d_batch[i]) (void)hipFree(d_batch[i]); if (pipeStream[i]) (void)hipStreamDestroy(pipeStream[i]); }
@@ -604,8 +618,9 @@ constexpr uint32_t kLdsBudgetBytes = 160 * 1024 - 2048 - 23 * 1024 * 4;     // 1
 constexpr uint64_t kMaxWorkItems = 0xFFFFFFFFull - ((uint64_t)1 << 22);
 
 template <bool STATS>
-void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStream_t stream, const WaveExtras& ex = WaveExtras{}, uint32_t wgCap = 0) {
+void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStream_t stream, const WaveExtras& ex = WaveExtras{}, uint32_t wgCap = 0, uint32_t unitsHere = 0) {
   LaunchSlot& slot = S.slotFor(stream);
+  const uint32_t units = unitsHere ? unitsHere : S.cus();      // (a CU-masked stream: the units of its mask)
   uint32_t* workCounter = slot.d_workCounter;
   const DeviceScene dsv = S.view();
   // Streams are walked in 8x8 pixel tiles of window-width rows (a whole window, a batch of it, or one rank's
@@ -661,12 +676,12 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
     auto grid = [&](auto kern, uint32_t threads, size_t ldsBytes) {
       uint32_t perUnit = S.residentBlocks(reinterpret_cast<const void*>(kern), (int)threads, ldsBytes);
       if (wgCap) perUnit = std::min(perUnit, wgCap);      // (NIF renders: a trace launch that runs beside the previous batch's MLP)
-      uint64_t wgs = std::min<uint64_t>((items + threads - 1) / threads, (uint64_t)S.cus() * perUnit);
+      uint64_t wgs = std::min<uint64_t>((items + threads - 1) / threads, (uint64_t)units * perUnit);
       if (!plain) wgs = std::min<uint64_t>(wgs, kMaxSlotWorkgroups);      // (the escaped-slot list has padding for that many)
       return (uint32_t)wgs;
     };
     auto go = [&](auto kern) {
-      if (S.opt.sayGrid) fprintf(stderr, "mi_raylib: grid %u workgroups = %u units x %u resident\n", grid(kern, 256, 0), S.cus(), S.residentBlocks(reinterpret_cast<const void*>(kern), 256, 0));
+      if (S.opt.sayGrid) fprintf(stderr, "mi_raylib: grid %u workgroups = %u units x %u resident\n", grid(kern, 256, 0), units, S.residentBlocks(reinterpret_cast<const void*>(kern), 256, 0));
       hipLaunchKernelGGL(kern, dim3(grid(kern, 256, 0)), dim3(256), 0, stream, dsv, d_rays, cnt, workCounter, 0u, S.opt.tune, tileW, exs);
     };
     if (S.opt.doubleFallback) {
@@ -750,6 +765,33 @@ void launchWavefront(mi_scene& S, mi_trace_result* d_rays, uint32_t cnt, hipStre
   }
 }
 
+// Option "nif_split": the two CU-masked streams of a NIF render (made once per value; 0 = none, also when the runtime refuses
+// masked streams - said once on stderr: the render then shares the chip between its launches as without the option).
+// Returns the units the trace stream owns.
+uint32_t splitStreams(mi_scene& S) {
+  const uint32_t N = (uint32_t)S.numCUs;
+  uint32_t x = S.opt.nifSplit;
+  if (x == 0 || S.splitRefused) return 0;
+  if (x > N / 2) x = N / 2;
+  if (S.splitUnits == x) return x;
+  for (hipStream_t* q : {&S.nifSplitMlp, &S.nifSplitTrace}) if (*q) { (void)hipStreamSynchronize(*q); (void)hipStreamDestroy(*q); *q = nullptr; }
+  S.splitUnits = 0;
+  std::vector<uint32_t> lo((N + 31) / 32, 0u), hi((N + 31) / 32, 0u);
+  for (uint32_t i = 0; i < N; ++i) (i < N - x ? lo : hi)[i / 32] |= 1u << (i % 32);
+  const hipError_t e0 = hipExtStreamCreateWithCUMask(&S.nifSplitMlp, (uint32_t)lo.size(), lo.data());
+  const hipError_t e1 = e0 == hipSuccess ? hipExtStreamCreateWithCUMask(&S.nifSplitTrace, (uint32_t)hi.size(), hi.data()) : e0;
+  if (e1 != hipSuccess) {
+    (void)hipGetLastError();
+    if (S.nifSplitMlp) { (void)hipStreamDestroy(S.nifSplitMlp); S.nifSplitMlp = nullptr; }
+    S.nifSplitTrace = nullptr; S.splitRefused = true;
+    fprintf(stderr, "mi_raylib: option nif_split: no compute-unit masked streams here (%s); the render's launches share the chip\n", hipGetErrorString(e1));
+    return 0;
+  }
+  if (!S.splitFirst) HIP_CHECK(hipEventCreateWithFlags(&S.splitFirst, hipEventDisableTiming));
+  S.splitUnits = x;
+  return x;
+}
+
 void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipStream_t stream) {
   if (n == 0) return;
   if (n > 0xFFFFFFFFull) throw ArgError("mi_render: more than 2^32-1 rays in one call");
@@ -793,34 +835,68 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
         // only when the MLP + accumulate that read it are done; the render's stream ends behind the last of them.
         const bool two = S.opt.nifOverlap && S.nifSlots[1].u != nullptr;
         if (two && !S.nifAux) HIP_CHECK(hipStreamCreateWithFlags(&S.nifAux, hipStreamNonBlocking));
-        hipStream_t mlpStream = two ? S.nifAux : stream;
+        // Option "nif_split" = x: the trace launches of batches 1.. run on x compute units of their own and the MLP + accumulate
+        // passes on the other numCUs - x (two CU-masked streams), instead of sharing the chip. Batch 0's trace launch has the
+        // device to itself and stays on the render's stream, which the masked trace stream follows (an event) and which
+        // follows both again when the render ends. Only the SCHEDULE changes: same kernels, same buffers, same order per buffer.
+        const uint32_t splitX = (two && S.opt.cus == 0 && S.ds.samplesPerPixel > 2u * S.scratchSamples) ? splitStreams(S) : 0u;
+        hipStream_t mlpStream = splitX ? S.nifSplitMlp : two ? S.nifAux : stream;
+        // (the MLP keeps its grid of one workgroup per unit of the whole chip: a mask that leaves the shader engines unequal - any x that
+        // is not a multiple of their number - still gets the same share of workgroups per engine from the dispatcher, and with a grid
+        // of only numCUs - x some units of the fuller engines would idle. The workgroups that find no unit free start when the first
+        // ones leave, and leave at once: passes are drawn, nif_asm_kernel.hpp)
+        const uint32_t mlpUnits = S.cus();
         uint32_t b = 0;
+        mi_scene::NifSlots* pendQ = nullptr; uint32_t pendSc = 0, pendSegBase = 0;      // (nif_split: the batch whose accumulate pass is still to be enqueued)
+        auto flushAccumulate = [&](hipStream_t on) {
+          if (!pendQ) return;
+          HIP_CHECK(hipStreamWaitEvent(on, pendQ->done, 0));
+          hipLaunchKernelGGL(nif_accumulate_kernel, grid, block, 0, on, d_rays, cnt, pendSc, segShift, pendSegBase, pendQ->color, pendQ->tp, pendQ->u, pendQ->bgr);
+          pendQ = nullptr;
+        };
         try {
         for (uint32_t s0 = 0; s0 < S.ds.samplesPerPixel; s0 += S.scratchSamples, ++b) {
           mi_scene::NifSlots& q = S.nifSlots[two ? (b & 1u) : 0u];
           const uint32_t sc = std::min<uint32_t>(S.scratchSamples, S.ds.samplesPerPixel - s0);
-          if (two && q.donePending) { HIP_CHECK(hipStreamWaitEvent(stream, q.done, 0)); q.donePending = false; }
-          HIP_CHECK(hipMemsetAsync(q.count, 0, sizeof(uint32_t), stream));
+          hipStream_t ts = (splitX && b > 0) ? S.nifSplitTrace : stream;          // this batch's trace launch
+          if (splitX && b == 1) { HIP_CHECK(hipEventRecord(S.splitFirst, stream)); HIP_CHECK(hipStreamWaitEvent(ts, S.splitFirst, 0)); }
+          if (two && q.donePending) { HIP_CHECK(hipStreamWaitEvent(ts, q.done, 0)); q.donePending = false; }
+          HIP_CHECK(hipMemsetAsync(q.count, 0, sizeof(uint32_t), ts));
           WaveExtras ex;
           ex.sampleCount = sc; ex.segments = (sc + segLen - 1) / segLen; ex.segBase = s0 / segLen;     // (pixel, segment) atoms
           ex.u = q.u; ex.v = q.v; ex.slotColor = q.color; ex.slotTp = q.tp;
           ex.index = q.index; ex.count = q.count; ex.azimuthRotation = radians;
-          const uint32_t wgCap = (two && b > 0) ? S.opt.nifTraceWgs : 0u;       // batch 0 has the device to itself
-          if (S.opt.fullStats) launchWavefront<true>(S, d_rays, cnt, stream, ex, wgCap);
-          else launchWavefront<false>(S, d_rays, cnt, stream, ex, wgCap);
-          if (two) { HIP_CHECK(hipEventRecord(q.traced, stream)); HIP_CHECK(hipStreamWaitEvent(mlpStream, q.traced, 0)); }
+          ex.firstInSetup = S.opt.nifFirstTest ? 1u : 0u;
+          const uint32_t wgCap = (two && b > 0 && !splitX) ? S.opt.nifTraceWgs : 0u;       // batch 0 has the device to itself
+          const uint32_t unitsHere = (splitX && b > 0) ? splitX : 0u;
+          if (S.opt.fullStats) launchWavefront<true>(S, d_rays, cnt, ts, ex, wgCap, unitsHere);
+          else launchWavefront<false>(S, d_rays, cnt, ts, ex, wgCap, unitsHere);
+          if (two) { HIP_CHECK(hipEventRecord(q.traced, ts)); HIP_CHECK(hipStreamWaitEvent(mlpStream, q.traced, 0)); }
+          if (splitX) flushAccumulate(ts);
           std::pair<hipEvent_t, hipEvent_t> tm{nullptr, nullptr};
           if (S.opt.nifTiming) { HIP_CHECK(hipEventCreate(&tm.first)); HIP_CHECK(hipEventCreate(&tm.second)); S.nifTimes.push_back(tm); HIP_CHECK(hipEventRecord(tm.first, mlpStream)); }
-          nif_launch_mlp(S.nif, q.u, q.v, q.index, q.count, cnt * sc, q.bgr, nullptr, mlpStream, true, S.opt.nifShape, S.cus(), S.opt.nifGenerations);
+          nif_launch_mlp(S.nif, q.u, q.v, q.index, q.count, cnt * sc, q.bgr, nullptr, mlpStream, true, S.opt.nifShape, mlpUnits, S.opt.nifGenerations);
           if (tm.second) HIP_CHECK(hipEventRecord(tm.second, mlpStream));
-          hipLaunchKernelGGL(nif_accumulate_kernel, grid, block, 0, mlpStream, d_rays, cnt, sc, segShift, ex.segBase, q.color, q.tp, q.u, q.bgr);
-          if (two) { HIP_CHECK(hipEventRecord(q.done, mlpStream)); q.donePending = true; }
+          if (splitX) {
+            // the accumulate pass of this batch goes BEHIND the next batch's trace launch on the trace stream (which idles there until
+            // the MLP is done; the set is traced into again only after it, by stream order): the MLP stream runs MLPs back to back
+            HIP_CHECK(hipEventRecord(q.done, mlpStream));
+            pendQ = &q; pendSc = sc; pendSegBase = ex.segBase;
+          } else {
+            hipLaunchKernelGGL(nif_accumulate_kernel, grid, block, 0, mlpStream, d_rays, cnt, sc, segShift, ex.segBase, q.color, q.tp, q.u, q.bgr);
+            if (two) { HIP_CHECK(hipEventRecord(q.done, mlpStream)); q.donePending = true; }
+          }
+        }
+        if (splitX) {
+          flushAccumulate(b > 1 ? S.nifSplitTrace : stream);
+          if (b > 1) { HIP_CHECK(hipEventRecord(S.splitFirst, S.nifSplitTrace)); HIP_CHECK(hipStreamWaitEvent(stream, S.splitFirst, 0)); }
         }
         if (two) for (mi_scene::NifSlots& q : S.nifSlots) if (q.donePending) { HIP_CHECK(hipStreamWaitEvent(stream, q.done, 0)); q.donePending = false; }
         } catch (...) {
           // a launch or a HIP call failed with MLP / accumulate passes queued on nifAux: they write the caller's rgb, so the
           // error must not return while they run behind the caller's stream (mi_render_device) - wait for them here
           if (two) { (void)hipStreamSynchronize(S.nifAux); for (mi_scene::NifSlots& q : S.nifSlots) q.donePending = false; }
+          if (splitX) { (void)hipStreamSynchronize(S.nifSplitTrace); (void)hipStreamSynchronize(S.nifSplitMlp); }
           throw;
         }
       } else {

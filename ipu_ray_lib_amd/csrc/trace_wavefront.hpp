@@ -75,6 +75,7 @@ struct WaveExtras {
   // (pixel_coords_kernel): an atom's FETCH then reads 8 contiguous bytes instead of pulling a 64-byte sector of the 84-byte
   // record out of HBM - sixteen times per pixel at 1000 spp, which was most of the frame's HBM traffic.
   const float2* coords = nullptr;
+  uint32_t firstInSetup = 1;     // slot-mode launches: a cast's first box test runs in the turn that sets the cast up (scene option "nif_first_test"; 0 = in a NODE turn, for A/B)
 };
 
 // SPEC: a lane whose walk reaches a primitive whose box it hits does not wait for the LEAF turn: it notes the primitive
@@ -109,7 +110,10 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
 }
 
 // entries of the escaped-slot list a wave reserves at a time (slot mode; the host sizes the list for the padding: raylib.hip)
-constexpr uint32_t kEnvChunk = 256;
+constexpr uint32_t kEnvChunk = 2048;     // entries of the escaped-slot list a wave reserves per atomic (a multiple of kEnvBlock)
+constexpr uint32_t kEnvBlock = 256;      // what a wave has left of its last reservation when it runs out of work: the block it stands in is padded with a slot it wrote
+                                         // before, every further whole block is filled with kEnvHole - entries no MLP kernel evaluates (nif_kernels.hpp kNifHole)
+constexpr uint32_t kEnvHole = 0xFFFFFFFFu;
 
 constexpr WaveTune kDefaultTune = {8, 16, 24, 48, 3, 4, 6, 1, 1, 40, 0};      // re-swept on the round-3 kernel on two scenes (profiles/r03_kernel_ab.txt): a cheaper box test favours one more of them per vote
 // DF: the reference's ALLOW_DOUBLE_FALLBACK=1 build of the triangle test (trace_kernels.hpp). FAST: the tolerance tier
@@ -125,6 +129,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
                                                                    uint32_t* workCounter, uint32_t ldsNodeCount, WaveTune tuneArg, uint32_t tileStreamW, WaveExtras ex) {
   const WaveTune tune = FIXED_TUNE ? kDefaultTune : tuneArg;
   const bool slots = (SLOTS == 2) ? (ex.slotColor != nullptr) : (SLOTS == 1);
+  constexpr bool kFirstInSetup = SLOTS != 0 && MERGE && !SPEC && !FAST && !LDS_NODES && !DF;      // (see the cast set-up of the merged SHADE / GEN turn)
   __shared__ float sinTbl[92];
   // the materials a hit is shaded with, when the scene has few (the built-in scenes have 8, test_scene.dae 9): SHADE
   // otherwise waits for two dependent global loads, leaf record then material
@@ -667,6 +672,31 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
         hit.t = kInf; hit.leaf = 0xFFFFFFFFu;
         { uint32_t seen; node = root_start(sc, o, seen) << 5; if (STATS) cs.nodes += seen; }
         ph = (numNodes > 0) ? PH_NODE : PH_SHADE;
+        // Slot-mode launches (NIF renders): the cast's FIRST box test runs here, in the turn that set the cast up, instead of in a
+        // NODE turn. In the open scenes an environment light is for, most casts miss the root's box: they used to take a NODE turn
+        // each for that one test - next to the few lanes that walk the mesh, 11.7 NODE turns per 64 casts at 20 % occupancy in
+        // config 5 - and now go from set-up to SHADE without one, while the walking lanes collect until a NODE turn pays. The same
+        // test on the same values as nodeBodyT below, the walk continues from its outcome: nothing a path computes changes.
+        if constexpr (kFirstInSetup) {
+          if (slots && ex.firstInSetup && ph == PH_NODE) {
+            const GNode nd = *reinterpret_cast<const GNode*>(reinterpret_cast<const char*>(sc.nodes) + node);
+            if (STATS) cs.nodes++;
+            const float ax = (nd.minx - o.x) * inv.x, bx = (nd.maxx - o.x) * inv.x;
+            const float ay = (nd.miny - o.y) * inv.y, by = (nd.maxy - o.y) * inv.y;
+            const float az = (nd.minz - o.z) * inv.z, bz = (nd.maxz - o.z) * inv.z;
+            float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
+            float t1 = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * kSlabScale, hit.t);
+            if (exactSlab) {      // (the reference's literal compare / select sequence: NaN cases stay bit-identical)
+              t0 = 0.f; t1 = hit.t;
+              { float tmin = ax, tmax = bx; if (tmin > tmax) { const float w = tmin; tmin = tmax; tmax = w; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
+              { float tmin = ay, tmax = by; if (tmin > tmax) { const float w = tmin; tmin = tmax; tmax = w; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
+              { float tmin = az, tmax = bz; if (tmin > tmax) { const float w = tmin; tmin = tmax; tmax = w; } tmax *= kSlabScale; t0 = tmin > t0 ? tmin : t0; t1 = tmax < t1 ? tmax : t1; }
+            }
+            node = !(t0 > t1) ? nd.hit : nd.link;
+            ph = (node & kLeafFlag) ? PH_LEAF : ((node >= numNodes) ? PH_SHADE : PH_NODE);
+            node &= ~kLeafFlag;
+          }
+        }
       }
       if (wasShade || wasGen) pathStore();
       paths += (uint32_t)__popcll(__ballot(pathEnd));
@@ -820,7 +850,10 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
       if (STATS) tGen += __builtin_amdgcn_s_memtime() - tq2;
     }
   }
-  if (slots) for (uint32_t k = envNext + lane; k < envEnd; k += 64u) ex.index[k] = envFill;      // the rest of the wave's last chunk
+  if (slots) {      // the rest of the wave's last reservation: its block padded, the blocks behind it marked as holes
+    const uint32_t padEnd = min(envEnd, (envNext + kEnvBlock - 1u) & ~(kEnvBlock - 1u));
+    for (uint32_t k = envNext + lane; k < envEnd; k += 64u) ex.index[k] = k < padEnd ? envFill : kEnvHole;
+  }
   flush_stats(sc, lane == 0 ? casts : 0u, cs, lane == 0 ? paths : 0u);
   if (STATS && lane == 0) {
     atomicAdd(&sc.counters[4], (unsigned long long)itN); atomicAdd(&sc.counters[5], (unsigned long long)lnN);

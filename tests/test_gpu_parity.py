@@ -552,6 +552,64 @@ def test_config5_monkey_with_nif_environment():
     dev.close()
 
 
+def test_nif_render_schedule_options_leave_every_byte_alone():
+    """What only changes the SCHEDULE of a NIF render must not change a byte of its result: the trace launches of batches 1.. on
+    compute units of their own (option nif_split: CU-masked streams; 8 and 24 leave the shader engines unequal, which the MLP's
+    drawn passes absorb; the accumulate passes move to the trace stream) and the cast's first box test in a NODE turn instead of
+    the turn that sets the cast up (nif_first_test = 0). Config 5's scene and network (K3a runs), fifteen sample batches of four."""
+    rng = np.random.default_rng(8)
+    ks, bs, relu = _nif_weights(rng)
+    mean = np.array([-2.3514461517333984, -2.2660605907440186, -1.9648972749710083], np.float32) - np.float32(1e-8)
+    s = irl.HostScene.builtin("monkey")
+    d = s.desc
+    d.set_image(96, 72); d.samples_per_pixel = 58
+
+    def render(**opts):
+        dev = irl.IpuScene(d).set_option("nif_spl", 4)
+        for k, v in opts.items():
+            dev.set_option(k, v)
+        dev.setNif(ks, bs, relu, 12, 3.4299468994140625, mean, True)
+        rays = s.init_ray_stream()
+        dev.run(rays, irl.MODE_PATH_TRACE)
+        again = s.init_ray_stream()
+        dev.run(again, irl.MODE_PATH_TRACE)          # (the streams and the pass counters are the scene's: a second render finds them in order)
+        dev.close()
+        assert_streams_identical(again, rays, f"second render with {opts}")
+        return rays
+
+    base = render()
+    assert (base["h"]["flags"] & irl.FLAG_ESCAPED).mean() > 0.5 and np.isfinite(np.stack([base["rgb"][k] for k in "xyz"], 1)).all()
+    for opts in ({"nif_split": 32}, {"nif_split": 8}, {"nif_split": 24}, {"nif_first_test": 0}, {"nif_split": 24, "nif_first_test": 0}, {"nif_overlap": 0}):
+        assert_streams_identical(render(**opts), base, f"NIF render with {opts}")
+
+
+@pytest.mark.parametrize("shape", ["w6", "a8", "b4", "r8"])
+def test_nif_render_with_every_mlp_kernel_skips_the_lists_holes(shape):
+    """The trace kernel reserves room in the escaped-slot list 2 048 entries at a time; what a wave leaves unused of its last
+    reservation is one padded block and HOLES (whole 256-entry blocks of 0xFFFFFFFF). Every MLP kernel must pass them over -
+    no coordinate read, no result written - so a small render (a hundred waves, each leaving up to seven blocks of holes) gives,
+    with each of them, the oracle's hit records bit for bit and its rgb within the MLP tolerance."""
+    rng = np.random.default_rng(8)
+    ks, bs, relu = _nif_weights(rng)
+    mean = np.array([-2.3514461517333984, -2.2660605907440186, -1.9648972749710083], np.float32) - np.float32(1e-8)
+    s = irl.HostScene.builtin("monkey")
+    d = s.desc
+    d.set_image(128, 96); d.samples_per_pixel = 4
+    dev = irl.IpuScene(d, variants=shape.startswith("r")).set_option("nif_shape", shape)
+    dev.setNif(ks, bs, relu, 12, 3.4299468994140625, mean, True)
+    got = s.init_ray_stream(); want = got.copy()
+    dev.run(got, irl.MODE_PATH_TRACE)
+    nif, keep = ol.make_nif(ks, bs, relu, 12, 3.4299468994140625, mean, True, half_features=True, half_weights_acts=True)
+    st = ol.Stats()
+    ol.lib().o_path_trace_nif_pixel_rng(C.byref(d), C.byref(nif), 0.0, want.ctypes.data, want.size, 16, C.byref(st))
+    assert rows_differing(np.ascontiguousarray(got["h"]), np.ascontiguousarray(want["h"])).size == 0
+    g = np.stack([got["rgb"][k] for k in "xyz"], 1); w = np.stack([want["rgb"][k] for k in "xyz"], 1)
+    assert np.isfinite(g).all()
+    err = np.abs(g - w) / (np.abs(w) + 0.05)
+    assert np.quantile(err, 0.995) < 0.03 and err.max() < 0.3, (np.quantile(err, 0.995), err.max())
+    dev.close()
+
+
 def test_nif_path_trace_against_oracle(scenes):
     """Per-sample loop trace -> uv -> MLP -> env add (src/IpuScene.cpp:571-583) on the 'spheres' scene (open
     environment, as in the reference's NIF demo). Hit records are bit exact; rgb within the MLP tolerance

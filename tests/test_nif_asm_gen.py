@@ -122,16 +122,8 @@ def replay(kinds, relu, mt=2, nw=8, **kw):
                 assert addr == "%[biasv]"
                 content = ("bias", off)
                 dest = regs_of(args[0])
-                if dest is None:                       # K3b: the final layer's bias straight into an output operand
-                    assert re.match(r"%\[o\d\]$", args[0])
-                    dest = [("o", int(args[0][3]))]
-                else:
-                    assert not in_flight(dest), f"line {ln}: read into registers with a read in flight"
-                    if mt != 2:                        # K3b: into an accumulator, whose previous pair must have been converted
-                        assert acc_lo <= dest[0][1] < acc_hi and dest[0][0] == "v"
-                        st = acc_state.get(dest[0])
-                        assert st is None or st.get("converted"), f"line {ln}: bias loaded into an accumulator that is not converted yet"
-                        acc_state[dest[0]] = dict(bias=off, steps=0, converted=False)
+                assert dest == [(L.bias(0)[0], L.bias(0)[1] + k) for k in range(4)] or dest == [(L.bias(1)[0], L.bias(1)[1] + k) for k in range(4)]
+                assert not in_flight(dest), f"line {ln}: read into registers with a read in flight"
             pending.append((dest, content))
             assert len(pending) <= 15
             continue
@@ -169,40 +161,29 @@ def replay(kinds, relu, mt=2, nw=8, **kw):
                 assert b_ == f"%[f{ks - act_steps}{m}]", (ln, b_)
             tile = 0 if last else 2 * j + tt
             want_bias = ("bias", 4 * net.bias_base[l] + 64 * tile)
-            if last:
+            if last and mt == 2:
                 assert d_ == f"%[o{m}]"
                 rd_ = [("o", m)]
+            elif last:
+                rd_ = regs_of(d_)
+                assert rd_ == [("v", gen.ACC + 4 * m + k) for k in range(4)], "K3b's outputs are tied to v[160:175]"
+                st0 = acc_state.get(rd_[0])
+                assert st0 is None or st0.get("converted") or ks > 0, f"line {ln}: the final layer writes an accumulator that is not converted yet"
             else:
                 rd_ = regs_of(d_)
                 assert rd_[0][0] == "v" and acc_lo <= rd_[0][1] < acc_hi
-            if mt == 2:
-                if ks == 0:
-                    rc = regs_of(c_)
-                    assert not in_flight(rc)
-                    assert all(holds.get(r) == want_bias for r in rc), f"line {ln}: C operand {holds.get(rc[0])}"
-                    if not last:
-                        st = acc_state.get(rd_[0])
-                        assert st is None or st.get("converted"), f"line {ln}: accumulator rewritten before its epilogue"
-                        acc_state[rd_[0]] = dict(l=l, j=j, tt=tt, m=m, steps=1, last=n_mfma, converted=False)
-                else:
-                    assert c_ == d_
-                    if not last:
-                        st = acc_state[rd_[0]]
-                        assert (st["l"], st["j"], st["tt"], st["m"]) == (l, j, tt, m) and st["steps"] == ks
-                        st["steps"] += 1; st["last"] = n_mfma
+            if ks == 0:
+                rc = regs_of(c_)
+                assert rc[0][0] == "v", "an MFMA's C and D operands share a register file"
+                assert not in_flight(rc)
+                assert all(holds.get(r) == want_bias for r in rc), f"line {ln}: C operand {holds.get(rc[0])}"
+                if not last:
+                    st = acc_state.get(rd_[0])
+                    assert st is None or st.get("converted"), f"line {ln}: accumulator rewritten before its epilogue"
+                    acc_state[rd_[0]] = dict(l=l, j=j, tt=tt, m=m, steps=1, last=n_mfma, converted=False)
             else:
-                # K3b: every MFMA accumulates; the first one of a pair finds the bias in its accumulator, landed
                 assert c_ == d_
-                if ks == 0:
-                    assert not in_flight(rd_), f"line {ln}: the bias of the accumulator has not landed"
-                    assert all(holds.get(r) == want_bias for r in rd_), f"line {ln}: accumulator holds {holds.get(rd_[0])}, wanted {want_bias}"
-                    for r in rd_:
-                        holds[r] = None
-                    if not last:
-                        st = acc_state[rd_[0]]
-                        assert st["steps"] == 0
-                        st.update(l=l, j=j, tt=tt, m=m, steps=1, last=n_mfma)
-                elif not last:
+                if not last:
                     st = acc_state[rd_[0]]
                     assert (st["l"], st["j"], st["tt"], st["m"]) == (l, j, tt, m) and st["steps"] == ks
                     st["steps"] += 1; st["last"] = n_mfma
@@ -225,7 +206,7 @@ def replay(kinds, relu, mt=2, nw=8, **kw):
                 assert dst == final, (ln, dst, final)
                 act[dst] = (st["l"], st["j"], st["m"], idx, False)
             else:
-                assert dst[0] == "v" and 224 <= dst[1] < 232, f"line {ln}: a convert for the accumulator-file set goes through a temporary"
+                assert dst[0] == "v" and 224 <= dst[1] < 228, f"line {ln}: a convert for the accumulator-file set goes through a temporary"
                 tmp[dst] = (st["l"], st["j"], st["m"], idx, False)
             st.setdefault("cv", set()).add(half)
             if len(st["cv"]) == 2:
@@ -234,7 +215,7 @@ def replay(kinds, relu, mt=2, nw=8, **kw):
         if op == "v_pk_max_f16":
             dst = regs_of(args[0])[0]
             assert regs_of(args[1])[0] == dst and args[2] == "0"
-            where = act if dst in act and not (224 <= dst[1] < 232 and dst[0] == "v" and mt != 2) else tmp
+            where = act if dst in act and not (224 <= dst[1] < 228 and dst[0] == "v" and mt != 2) else tmp
             l0, j0, m0_, k0, r0 = where[dst]
             assert relu[l0] and not r0
             where[dst] = (l0, j0, m0_, k0, True)
@@ -266,7 +247,7 @@ def test_generated_body_replays(kinds):
 
 @pytest.mark.parametrize("kinds", ["FPPCPPL", "FPL", "FCPM"])
 def test_generated_body_of_the_four_wave_shape_replays(kinds):
-    """K3b: four waves of 64 rays, one activation set, the fragment ring in the accumulator file, the bias loaded into the accumulators."""
+    """K3b: four waves of 64 rays, one activation set and the fragment ring in the accumulator file."""
     relu = [True] * (len(kinds) - 1) + [False]
     n_mfma, n_lines = replay(kinds, relu, mt=4, nw=4)
     per_tile = {"F": 40, "P": 200, "C": 240, "L": 10, "M": 12}
@@ -277,3 +258,58 @@ def test_generated_body_other_placements_replay():
     relu = [True, True, False, True, True, True, False]
     replay("FPPCPPL", relu, dma_at=(2, 5, 9, 14, 20), epi_start=6)
     replay("FPPCPPL", relu, mt=4, nw=4, epi_start=6)
+
+
+HIPCC = __import__("shutil").which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not available")
+def test_compiled_statements_keep_their_operands_out_of_the_named_registers(tmp_path):
+    """What the replay cannot see: where hipcc PUT the statement's operands. The bodies name v0 - v216 (K3a) / v0 - v236 and a0 - a175
+    (K3b) literally; every operand the compiler allocates - the feature fragments, the two addresses, K3a's outputs - must lie outside
+    them (they are clobbers, or early-clobber tied outputs: an input that shares a register with one is overwritten in the first lines
+    of the statement - that happened once, with a memory fault for a result). Compiles the device code to assembly (no GPU) and reads
+    the operands back from the first lines of each statement; also: no scratch access and no compiler instruction inside a statement."""
+    import subprocess
+    out = tmp_path / "raylib.s"
+    cmd = [HIPCC, "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wno-unused-function",
+           "-I", str(ROOT / "include"), "-S", "--cuda-device-only", "-o", str(out), str(ROOT / "ipu_ray_lib_amd" / "csrc" / "raylib.hip")]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=900)
+    text = out.read_text()
+    seen = 0
+    for mt, last_v, last_a in ((2, gen.Lay(2, 8).last_v, -1), (4, gen.Lay(4, 4).last_v, gen.Lay(4, 4).last_a)):
+        m = re.search(r"^(_ZN2mi14nif_asm_kernelILj%dE\w*):" % mt, text, re.M)
+        assert m, f"nif_asm_kernel<{mt}> not found"
+        body = text[text.index(m.group(1) + ":"):]
+        body = body[:body.index(".Lfunc_end")].split("\n")
+        starts = [i for i, l in enumerate(body) if "ASMSTART" in l]
+        ends = [i for i, l in enumerate(body) if "ASMEND" in l]
+        a, b = max(zip(starts, ends), key=lambda t: t[1] - t[0])
+        stmt = [l.strip() for l in body[a + 1:b] if l.strip() and not l.strip().startswith(";")]
+        assert len(stmt) > 6000
+        named_v, named_a = set(range(last_v + 1)), set(range(last_a + 1))
+
+        def outside(tok, what):
+            r = regs_of(tok.split()[0])
+            assert r, (what, tok)
+            for f, k in r:
+                assert k not in (named_v if f == "v" else named_a), f"nif_asm_kernel<{mt}>: operand {what} = {tok} lies in the statement's named registers"
+
+        # lane16: source of the first v_add_u32 (chunk address) and of every LDS-DMA; biasv: address of the first bias read
+        va = next(l for l in stmt if l.startswith("v_add_u32"))
+        outside(va.split(",")[2].strip(), "lane16")
+        dma = next(l for l in stmt if l.startswith("global_load_lds_dwordx4"))
+        outside(dma.split()[1].rstrip(","), "lane16 (LDS-DMA)")
+        vaddr = va.split()[1].rstrip(",")
+        bias = next(l for l in stmt if l.startswith("ds_read_b128") and l.split(",")[1].split()[0] != vaddr)
+        outside(bias.split(",")[1].split()[0], "biasv")
+        # the feature fragments: B operands of the first layer's MFMAs (2 k-steps x mt ray tiles)
+        mf = [l for l in stmt if l.startswith("v_mfma")][:4 * mt]
+        for l in mf:
+            outside(l.split(",")[2].strip(), "a feature fragment")
+        if mt == 2:
+            for l in [l for l in stmt if l.startswith("v_mfma")][-2:]:
+                outside(l.split(",")[0].split(None, 1)[1].strip(), "an output")
+        assert not [l for l in stmt if l.startswith("scratch_") or l.startswith("buffer_")], "scratch access inside the statement"
+        seen += 1
+    assert seen == 2

@@ -25,7 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("n", nargs="?", type=int, default=1440 * 1440)
     ap.add_argument("--shape", default="auto", help="scene option nif_shape: auto (default: K3a for this network) | w6 | t6 | t4 (nif_mlp_kernel) | r8 | r8s (K3r, nif_regs_kernel.hpp) | a8 (K3a, nif_asm_kernel.hpp)")
-    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=20)
     a = ap.parse_args()
     n = a.n
     rng = np.random.default_rng(0)
@@ -35,9 +35,10 @@ def main():
     dev.setNif(ks, bs, relu, 12, 3.43, np.array([-2.35, -2.27, -1.96], np.float32), True)
     u = torch.rand(n, device="cuda"); v = torch.rand(n, device="cuda"); out = torch.empty(n, 3, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
-    for _ in range(2):
-        dev.nif_infer_device(u.data_ptr(), v.data_ptr(), out.data_ptr(), n, st)
+    dev.nif_infer_device(u.data_ptr(), v.data_ptr(), out.data_ptr(), n, st)
     torch.cuda.synchronize()
+    for _ in range(3):      # (no wait between these and the timed launches: an idle device needs ~1 ms to get its clocks back)
+        dev.nif_infer_device(u.data_ptr(), v.data_ptr(), out.data_ptr(), n, st)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = a.reps
     e0.record()

@@ -45,7 +45,7 @@ def build(specs):
     for p in procs: assert p.wait() == 0
 
 
-def run(rounds, reps, out):
+def run(rounds, reps, out, cus=()):
     import torch  # noqa: F401  (one HIP runtime per process, loaded first)
     libs = sorted(OUT.glob("lib_*.so"), key=lambda p: (p.stem != "lib_base", p.stem))
     rng = np.random.default_rng(0)
@@ -74,6 +74,14 @@ def run(rounds, reps, out):
         for k in names:
             lib, h = hs[k]
             times[k].append(lib.lab_time(h, 1, reps, 256))
+    # fewer workgroups than compute units (the rest of the chip idle): does the clock of a power-limited launch make up for the units left out?
+    if cus:
+        lib, h = hs[names[0]]
+        for c in cus:
+            ts = [lib.lab_time(h, 1, reps, c) for _ in range(3)]
+            buf = (C.c_ulonglong * 4)()
+            ghz = buf[0] / buf[1] * 0.1 if lib.lab_stamps(buf) == 0 and buf[1] else float("nan")
+            print(f"{names[0]} on {c:3d} workgroups: median {statistics.median(ts):.4f} ms  ({statistics.median(ts) * c / 256:.4f} ms x units / 256)  clock {ghz:.3f} GHz", flush=True)
     ref = None
     rec = {"rays": n, "rounds": rounds, "reps": reps, "builds": {}}
     for k, ts in times.items():
@@ -104,5 +112,6 @@ if __name__ == "__main__":
     else:
         import argparse
         ap = argparse.ArgumentParser(); ap.add_argument("cmd"); ap.add_argument("--rounds", type=int, default=5); ap.add_argument("--reps", type=int, default=20); ap.add_argument("--out", default="")
+        ap.add_argument("--cus", default="", help="also time the first build on these workgroup counts, e.g. 256,240,224")
         a = ap.parse_args()
-        run(a.rounds, a.reps, a.out)
+        run(a.rounds, a.reps, a.out, [int(c) for c in a.cus.split(",") if c])
