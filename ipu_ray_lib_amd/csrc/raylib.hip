@@ -92,6 +92,12 @@ const float* hostSinTable() {
 // Kernel selection and tuning of ONE scene: defaults, overridden by the MI_RAYLIB_* environment variables as they
 // stand when the scene is created (read once, into the scene) and by mi_scene_set_option afterwards. Nothing here is
 // process-global: creating or tuning scene B never changes what scene A launches.
+// Samples a NIF render traces per launch (option nif_spl; the default, memory permitting - ensureScratch). A launch of the persistent
+// kernel ends in a drain - lanes whose 64-sample work atom is the last the queue had wait for the longest one of their wave - and a
+// 1440^2 launch of 128 samples is only ten atoms per lane: config 5's trace launches took 22 ms per 128 samples that way, 15 with 256
+// per launch, 11 with 512 and no less with 768 or 1 024 (profiles/r05_config5_launch_ab.txt); 512 samples are 48 B x 512 per pixel, 51 GB
+// of a 1440^2 frame's 288.
+constexpr uint32_t kNifSplDefault = 512, kNifSplMax = 1024;
 struct SceneOptions {
   bool fullStats = false;          // MI_RAYLIB_FULL_STATS / "full_stats": instrumented kernel variants (node/leaf counters, phase occupancy)
   WaveTune tune = kDefaultTune;
@@ -114,7 +120,9 @@ struct SceneOptions {
   bool leafRot = true;             // "leaf_rot": scenes without vertex normals read primitive records pre-rotated for the cast's shear axis (GLeafRot: 18 selects per triangle test become 6; -2.4 %, profiles/r05_k1w_leaf_ab.txt)
   bool leanHit = true;             // "lean_hit": scenes without vertex normals run the default kernel's build that carries no barycentrics (BARY = false)
   bool coords = true;              // "coords": (pixel, segment) atoms read the pixel coordinates from a compact copy of the stream's (u, v)
-  bool nifOverlap = true;          // "nif_overlap": NIF renders trace sample batch b + 1 beside the MLP of batch b (two slot sets, second stream)
+  int nifOverlap = -1;             // "nif_overlap": NIF renders trace sample batch b + 1 beside the MLP of batch b (two slot sets, second stream): 1 | 0 | auto
+                                   // (-1, the default: only beside nif_mlp_kernel, whose workgroups come and go - K3a / K3b hold every register of their
+                                   // unit for the whole launch, nothing runs beside them, and the second slot set is memory better spent on longer launches)
   uint32_t nifTraceWgs = 0;        // "nif_trace_wgs": a NIF render's trace launch that runs beside the previous batch's MLP gets at most this many workgroups per
                                    // compute unit (0 = all that stay resident, the default: a cap of 1 paid 3 % while the trace launch queued behind its list
                                    // counter, and costs 0.7 % since it does not: profiles/r04_nif_overlap_ab.txt, r04_nif_trace_ab.txt)
@@ -193,13 +201,13 @@ struct SceneOptions {
     if (key == "cus") { if (!number(v, 0, 4096, q)) return false; cus = (uint32_t)q; return true; }
     if (key == "tiles") return flag01(v, tiles);
     if (key == "seg_budget_kb") { if (!number(v, 1, ~0ull >> 12, q)) return false; segBudgetKb = (size_t)q; return true; }
-    if (key == "nif_spl") { if (!number(v, 0, 128, q)) return false; nifSamplesPerLaunch = (uint32_t)q; return true; }
+    if (key == "nif_spl") { if (!number(v, 0, kNifSplMax, q)) return false; nifSamplesPerLaunch = (uint32_t)q; return true; }
     if (key == "pin") return flag01(v, pin);
     if (key == "nif_timing") return flag01(v, nifTiming);
     if (key == "nif_generations") { if (!number(v, 1, 4096, q)) return false; nifGenerations = (uint32_t)q; return true; }
     if (key == "root_start") return flag01(v, rootStart);
     if (key == "say_grid") return flag01(v, sayGrid);
-    if (key == "nif_overlap") return flag01(v, nifOverlap);
+    if (key == "nif_overlap") { if (!strcmp(v, "auto")) { nifOverlap = -1; return true; } bool on = false; if (!flag01(v, on)) return false; nifOverlap = on ? 1 : 0; return true; }
     if (key == "nif_first_test") return flag01(v, nifFirstTest);
     if (key == "nif_split") { if (!number(v, 0, 1024, q)) return false; nifSplit = (uint32_t)q; return true; }
     if (key == "nif_trace_wgs") { if (!number(v, 0, 16, q)) return false; nifTraceWgs = (uint32_t)q; return true; }
@@ -285,6 +293,8 @@ struct mi_scene {
   std::vector<LaunchSlot> slots;
   std::map<const void*, int> residentPerCU;      // workgroups of a kernel that stay resident on one compute unit (hipOccupancyMaxActiveBlocksPerMultiprocessor), asked once per kernel
   uint32_t cus() const { return opt.cus ? opt.cus : (uint32_t)numCUs; }
+  // (auto: beside nif_mlp_kernel, and whenever the trace launches are given compute units of their own - option nif_split)
+  bool nifOverlapOn() const { return opt.nifOverlap < 0 ? (opt.nifSplit > 0 || !((opt.nifShape >= 6 && opt.nifShape <= 8) && nif_asm_covers(nif.regs))) : opt.nifOverlap != 0; }
   // the scene as one launch sees it: option "root_start" decides whether the walk may start below the root
   DeviceScene view() const { DeviceScene v = ds; if (!opt.rootStart) v.rootInterior = 0; return v; }
   uint32_t residentBlocks(const void* kern, int threads, size_t ldsBytes) {
@@ -558,13 +568,13 @@ void ensureScratch(mi_scene& S, size_t n) {
   {
     const uint32_t asked = S.opt.nifSamplesPerLaunch;
     const uint32_t segLen = segment_samples(S.ds.samplesPerPixel);
-    uint32_t v = (asked >= 1 && asked <= 128) ? asked : 128u;
+    uint32_t v = (asked >= 1 && asked <= kNifSplMax) ? asked : kNifSplDefault;
     v = ((v + segLen - 1) / segLen) * segLen;
     v = std::min(v, std::max(segLen, ((S.ds.samplesPerPixel + segLen - 1) / segLen) * segLen));      // no more than the render has
     const bool haveTwo = S.nifSlots[1].u != nullptr;
-    auto setsFor = [&](uint32_t vv) { return (S.opt.nifOverlap && S.ds.samplesPerPixel > vv) ? 2u : 1u; };
+    auto setsFor = [&](uint32_t vv) { return (S.nifOverlapOn() && S.ds.samplesPerPixel > vv) ? 2u : 1u; };
     constexpr uint64_t kSlotBytes = 48;
-    uint64_t budget = (uint64_t)32 << 30;
+    uint64_t budget = (uint64_t)64 << 30;
     {
       size_t freeB = 0, totalB = 0;
       if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
@@ -572,15 +582,15 @@ void ensureScratch(mi_scene& S, size_t n) {
         budget = std::min<uint64_t>(budget, ((uint64_t)freeB + held) / 2);
       } else (void)hipGetLastError();
     }
-    if (!(asked >= 1 && asked <= 128))
+    if (!(asked >= 1 && asked <= kNifSplMax))
       while (v > segLen && (uint64_t)n * v * kSlotBytes * setsFor(v) > budget) v -= segLen;
     const bool oneSetOnly = setsFor(v) == 2u && (uint64_t)n * v * kSlotBytes * 2u > budget;      // two sets of the smallest launch do not fit
     // keep what is there when it still fits this stream and the request has not changed
     if (S.scratchRays >= n && S.scratchAsked == asked && S.scratchSamples >= segLen && S.scratchSamples % segLen == 0 &&
-        (haveTwo || oneSetOnly || !(S.opt.nifOverlap && S.ds.samplesPerPixel > S.scratchSamples))) return;
+        (haveTwo || oneSetOnly || !(S.nifOverlapOn() && S.ds.samplesPerPixel > S.scratchSamples))) return;
     S.scratchAsked = asked;
     S.scratchOneSet = oneSetOnly;
-    if (v != S.scratchSamples || (!haveTwo && !oneSetOnly && S.opt.nifOverlap && S.ds.samplesPerPixel > v)) { S.scratchSamples = v; S.scratchRays = 0; }     // slot buffers are sized for n x v (x two sets)
+    if (v != S.scratchSamples || (!haveTwo && !oneSetOnly && S.nifOverlapOn() && S.ds.samplesPerPixel > v)) { S.scratchSamples = v; S.scratchRays = 0; }     // slot buffers are sized for n x v (x two sets)
   }
   if (S.scratchRays >= n) return;
   if (S.nifPending) { HIP_CHECK(hipDeviceSynchronize()); S.nifPending = false; }      // an earlier NIF render may still read the old buffers
@@ -592,7 +602,7 @@ void ensureScratch(mi_scene& S, size_t n) {
   HIP_CHECK(hipMalloc(&S.d_rng, n * sizeof(Rng)));
   HIP_CHECK(hipMalloc(&S.d_segTotal, 3 * n * sizeof(float)));
   // the second set only where it is used: renders of more than one sample batch with the overlap on
-  const int sets = (S.opt.nifOverlap && S.ds.samplesPerPixel > S.scratchSamples && !S.scratchOneSet) ? 2 : 1;
+  const int sets = (S.nifOverlapOn() && S.ds.samplesPerPixel > S.scratchSamples && !S.scratchOneSet) ? 2 : 1;
   for (int k = 0; k < sets; ++k) {
     mi_scene::NifSlots& q = S.nifSlots[k];
     HIP_CHECK(hipMalloc(&q.u, slots * sizeof(float)));
@@ -833,7 +843,7 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
         // passes run in batch order on one stream and touch only rgb; the trace launch only reads the pixel coordinates and
         // writes the hit record of the same TraceResults (other dwords), so the two never meet. A set is traced into again
         // only when the MLP + accumulate that read it are done; the render's stream ends behind the last of them.
-        const bool two = S.opt.nifOverlap && S.nifSlots[1].u != nullptr;
+        const bool two = S.nifOverlapOn() && S.nifSlots[1].u != nullptr;
         if (two && !S.nifAux) HIP_CHECK(hipStreamCreateWithFlags(&S.nifAux, hipStreamNonBlocking));
         // Option "nif_split" = x: the trace launches of batches 1.. run on x compute units of their own and the MLP + accumulate
         // passes on the other numCUs - x (two CU-masked streams), instead of sharing the chip. Batch 0's trace launch has the

@@ -53,6 +53,8 @@ def one_gpu(d, scene, ks, bs, relu, steps, warmup, device=0, opts=""):
     if os.environ.get("MI_RAYLIB_FULL_STATS") == "1":
         p = dev.phase_stats(); cyc = p.pop("cycles")
         print("cycle shares:", {k: round(cyc[k] / cyc["total"], 3) for k in ("traverse", "shade", "gen")}, file=sys.stderr)
+        wc = c["casts"] / 64.0
+        print("turns per 64 casts / occupancy:", {k: (round(p[k]["iters"] / wc, 2), round(p[k]["lanes"] / (64.0 * max(p[k]["iters"], 1)), 3)) for k in ("node", "leaf", "shade", "gen")}, file=sys.stderr)
     dev.close()
     return res
 
