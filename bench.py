@@ -136,9 +136,10 @@ def config3_record(torch, irl, stream, spp=1000):
             "casts_per_s": c["casts"] / 2.0 / (ms * 1e-3), "paths_per_s": c["paths"] / 2.0 / (ms * 1e-3), "casts_per_path": c["casts"] / max(c["paths"], 1)}
 
 
-def config5_record(torch, irl, stream, cores, spp=256, check=True):
+def config5_record(torch, irl, stream, cores, spp=1024, check=True):
     """BASELINE config 5 (monkey bust + NIF environment, synthetic weights of the reference's 6 x 320 shape, 1440 x 1440 x 4000
-    spp) at `spp` samples on one GPU: one warm-up frame, one timed frame on a fresh stream; the MLP's share from HIP events round
+    spp) at `spp` samples on one GPU (1 024: the 64-sample work atoms and the 512-sample launches of the 4000-spp frame, two of its
+    eight launches): one warm-up frame, one timed frame on a fresh stream; the MLP's share from HIP events round
     every MLP launch (scene option nif_timing); rates as trace.cpp:328-333 defines them (paths/s = pixels x spp / s). Parity of
     the TIMED frame: every 4099th pixel against the oracle's NIF render - hit records bit for bit, rgb within the MLP's stated
     tolerance (tests/test_gpu_parity.py::test_config5_monkey_nif_1440_x_256spp_against_oracle)."""

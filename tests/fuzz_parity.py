@@ -128,15 +128,21 @@ def nif_campaign(budget, seed, max_cases=None, replay_case=None):
         d.max_path_length = int(rng.integers(1, 12)); d.roulette_start_depth = int(rng.integers(0, 6))
         hidden = int(rng.choice([32, 64, 128, 256, 320])); layers = int(rng.integers(2, 7))
         ks, bs, relu = nif_weights(rng, hidden, 12, layers)
-        spl = str(rng.choice(["1", "16", "32", "48", "64", "128", ""]))
+        spl = str(rng.choice(["1", "16", "32", "48", "64", "128", "256", "512", ""]))
         rot = float(rng.uniform(-180, 180))
+        # schedule options of the batched form (results must not depend on them): the next batch's trace launch beside the MLP or behind it,
+        # on compute units of its own (8 leaves the shader engines unequal), the cast's first box test in a NODE turn
+        sched = {"nif_overlap": str(rng.choice(["auto", "0", "1"])), "nif_split": str(rng.choice(["0", "0", "8", "32"])), "nif_first_test": str(rng.choice(["1", "1", "0"]))}
         desc = (f"case {case} (seed {seed}): {name} {w}x{h} spp={spp} rngseed={d.rng_seed} aa={d.anti_alias_scale} len={d.max_path_length} "
-                f"roulette={d.roulette_start_depth} mlp={layers}x{hidden} spl={spl or 'default'} rot={rot:.2f}")
+                f"roulette={d.roulette_start_depth} mlp={layers}x{hidden} spl={spl or 'default'} rot={rot:.2f} {sched}")
 
         def render(kernel):
             dev = irl.IpuScene(d, variants=kernel not in ("0", "1")).set_option("kernel", kernel)      # (kernel 3 lives in the variants build)
             if spl:
                 dev.set_option("nif_spl", spl)
+            if kernel != "0":
+                for k, v in sched.items():
+                    dev.set_option(k, v)
             dev.setNif(ks, bs, relu, 12, 3.43, np.array([-2.35, -2.26, -1.96], np.float32), True)
             dev.setHdriRotation(rot)
             rays = s.init_ray_stream()
