@@ -229,7 +229,9 @@ int mi_scene_set_ray_batch(mi_scene* scene, size_t rays_per_batch);
  *   "pool_tune"     "leafAt,burst,retireAt,refillMin,shadeW,genW[,dbl,maxExtra,leafThenNode,prio]"
  *   "tiles"         0 | 1           walk row-structured streams in 8x8 pixel tiles
  *   "seg_budget_kb" N >= 1          partial-sum buffer budget per launch
- *   "nif_spl"       0..128          NIF samples per launch (0 = default)
+ *   "nif_spl"       0..1024         NIF samples per launch, rounded up to whole segments (0 = default: 512, memory permitting - 48 B of
+ *                                   slots per sample and pixel; a launch short of work units ends in a long drain: 128 per launch cost
+ *                                   config 5 5 % of its frame)
  *   "nif_shape"     auto | a8 | b4 | w6 | t6 | t4    which NIF MLP kernel runs (b4 = K3a's dataflow with four waves of 64 rays: 3 % slower): auto (default) = a8 where its generated body covers the network
  *                                   (the reference's 6 x 320 shape), w6 otherwise; a8 = K3a, the hand-scheduled register-resident kernel
  *                                   (csrc/nif_asm_kernel.hpp); w6 | t6 | t4 = workgroup shapes of nif_mlp_kernel; the variants build also takes
@@ -238,7 +240,14 @@ int mi_scene_set_ray_batch(mi_scene* scene, size_t rays_per_batch);
  *   "root_start"    0 | 1           a cast whose origin lies strictly inside the root's box starts at node 1 (default 1; exact either way)
  *   "say_grid"      0 | 1           print every persistent launch's grid to stderr
  *   "pin"           0 | 1           page-lock the caller's stream for the duration of mi_render
- *   "nif_overlap"   0 | 1           NIF renders trace sample batch b + 1 beside the MLP of batch b (two slot sets, a second stream; default 1)
+ *   "nif_overlap"   auto | 0 | 1    NIF renders trace sample batch b + 1 beside the MLP of batch b (two slot sets, a second stream). auto (the
+ *                                   default) = only beside nif_mlp_kernel: K3a / K3b hold every register of their compute unit, nothing runs
+ *                                   beside them, and one slot set leaves the memory for longer launches
+ *   "nif_split"     0..1024         with the overlap: compute units the trace launches of batches 1.. get for themselves (two CU-masked
+ *                                   streams, hipExtStreamCreateWithCUMask; the MLP and accumulate passes keep the rest). 0 = off, the default:
+ *                                   the MLP is power-limited and loses as much as the hidden launch was worth (-2 ... +5 % by box)
+ *   "nif_first_test" 0 | 1          NIF renders: a cast's first box test runs in the turn that sets the cast up instead of in a NODE turn
+ *                                   (default 0: measured neutral)
  *   "nif_trace_wgs" 0..16           with nif_overlap: workgroups per compute unit of a trace launch that runs beside the previous batch's MLP
  *                                   (0 = all that stay resident, the default)
  *   "nif_timing"    0 | 1           bracket every MLP launch of a NIF render with HIP events (mi_get_nif_timing)

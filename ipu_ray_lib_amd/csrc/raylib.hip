@@ -129,7 +129,9 @@ struct SceneOptions {
   uint32_t nifSplit = 0;           // "nif_split": compute units a NIF render's trace launches of batches 1.. get for themselves (CU-masked streams: the MLP's
                                    // workgroups take every register of their unit, so a trace launch beside them otherwise only runs in their ramps and tails;
                                    // the MLP is power-limited and loses less than the units it gives up: DESIGN.md §6). 0 = no partition
-  bool nifFirstTest = true;        // "nif_first_test": a NIF render's casts take their first box test in the turn that sets them up (trace_wavefront.hpp kFirstInSetup; 0 = in a NODE turn, for A/B)
+  bool nifFirstTest = false;       // "nif_first_test": a NIF render's casts take their first box test in the turn that sets them up (trace_wavefront.hpp kFirstInSetup) instead of
+                                   // in a NODE turn. Measured neutral (config 5: NODE turns 11.0 -> 3.4 per 64 casts, SHADE turns 1.2 -> 2.1 at lower occupancy, frame +-0.05 %,
+                                   // profiles/r05_config5_launch_ab.txt): off by default, kept for A/B; results are the same either way
   bool nifTiming = false;          // "nif_timing": HIP events round every MLP launch of a NIF render (mi_get_nif_timing)
   uint32_t nifGenerations = kNifGenerations;   // MI_RAYLIB_NIF_GENERATIONS / "nif_generations": MLP workgroups launched per resident slot (nif_launch_mlp; measurement knob)
   bool rootStart = true;           // MI_RAYLIB_NO_ROOT_START / "root_start": a cast whose origin lies strictly inside the root's box starts at node 1

@@ -75,7 +75,7 @@ struct WaveExtras {
   // (pixel_coords_kernel): an atom's FETCH then reads 8 contiguous bytes instead of pulling a 64-byte sector of the 84-byte
   // record out of HBM - sixteen times per pixel at 1000 spp, which was most of the frame's HBM traffic.
   const float2* coords = nullptr;
-  uint32_t firstInSetup = 1;     // slot-mode launches: a cast's first box test runs in the turn that sets the cast up (scene option "nif_first_test"; 0 = in a NODE turn, for A/B)
+  uint32_t firstInSetup = 0;     // slot-mode launches: 1 = a cast's first box test runs in the turn that sets the cast up (scene option "nif_first_test") instead of in a NODE turn
 };
 
 // SPEC: a lane whose walk reaches a primitive whose box it hits does not wait for the LEAF turn: it notes the primitive
@@ -672,11 +672,13 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
         hit.t = kInf; hit.leaf = 0xFFFFFFFFu;
         { uint32_t seen; node = root_start(sc, o, seen) << 5; if (STATS) cs.nodes += seen; }
         ph = (numNodes > 0) ? PH_NODE : PH_SHADE;
-        // Slot-mode launches (NIF renders): the cast's FIRST box test runs here, in the turn that set the cast up, instead of in a
-        // NODE turn. In the open scenes an environment light is for, most casts miss the root's box: they used to take a NODE turn
-        // each for that one test - next to the few lanes that walk the mesh, 11.7 NODE turns per 64 casts at 20 % occupancy in
-        // config 5 - and now go from set-up to SHADE without one, while the walking lanes collect until a NODE turn pays. The same
-        // test on the same values as nodeBodyT below, the walk continues from its outcome: nothing a path computes changes.
+        // Slot-mode launches (NIF renders), option nif_first_test: the cast's FIRST box test runs here, in the turn that set the cast up,
+        // instead of in a NODE turn. In the open scenes an environment light is for, most casts miss the root's box: they take a NODE
+        // turn each for that one test - next to the few lanes that walk the mesh, 11 NODE turns per 64 casts at 20 % occupancy in
+        // config 5 - and with the option go from set-up to SHADE without one, while the walking lanes collect until a NODE turn pays.
+        // The same test on the same values as nodeBodyT below, the walk continues from its outcome: nothing a path computes changes.
+        // Measured neutral (the walking lanes sit out the SHADE turns instead: 2.1 of them per 64 casts at half occupancy against 1.2):
+        // off by default.
         if constexpr (kFirstInSetup) {
           if (slots && ex.firstInSetup && ph == PH_NODE) {
             const GNode nd = *reinterpret_cast<const GNode*>(reinterpret_cast<const char*>(sc.nodes) + node);

@@ -132,7 +132,7 @@ def nif_campaign(budget, seed, max_cases=None, replay_case=None):
         rot = float(rng.uniform(-180, 180))
         # schedule options of the batched form (results must not depend on them): the next batch's trace launch beside the MLP or behind it,
         # on compute units of its own (8 leaves the shader engines unequal), the cast's first box test in a NODE turn
-        sched = {"nif_overlap": str(rng.choice(["auto", "0", "1"])), "nif_split": str(rng.choice(["0", "0", "8", "32"])), "nif_first_test": str(rng.choice(["1", "1", "0"]))}
+        sched = {"nif_overlap": str(rng.choice(["auto", "0", "1"])), "nif_split": str(rng.choice(["0", "0", "8", "32"])), "nif_first_test": str(rng.choice(["0", "0", "1"]))}
         desc = (f"case {case} (seed {seed}): {name} {w}x{h} spp={spp} rngseed={d.rng_seed} aa={d.anti_alias_scale} len={d.max_path_length} "
                 f"roulette={d.roulette_start_depth} mlp={layers}x{hidden} spl={spl or 'default'} rot={rot:.2f} {sched}")
 

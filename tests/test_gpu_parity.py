@@ -555,8 +555,8 @@ def test_config5_monkey_with_nif_environment():
 def test_nif_render_schedule_options_leave_every_byte_alone():
     """What only changes the SCHEDULE of a NIF render must not change a byte of its result: the trace launches of batches 1.. on
     compute units of their own (option nif_split: CU-masked streams; 8 and 24 leave the shader engines unequal, which the MLP's
-    drawn passes absorb; the accumulate passes move to the trace stream), the cast's first box test in a NODE turn instead of
-    the turn that sets the cast up (nif_first_test = 0), the next batch's trace launch beside the MLP or behind it (nif_overlap;
+    drawn passes absorb; the accumulate passes move to the trace stream), the cast's first box test in the turn that sets the cast
+    up instead of a NODE turn (nif_first_test = 1), the next batch's trace launch beside the MLP or behind it (nif_overlap;
     auto = behind K3a), more samples per launch. Config 5's scene and network (K3a runs), fifteen sample batches of four."""
     rng = np.random.default_rng(8)
     ks, bs, relu = _nif_weights(rng)
@@ -580,7 +580,7 @@ def test_nif_render_schedule_options_leave_every_byte_alone():
 
     base = render()
     assert (base["h"]["flags"] & irl.FLAG_ESCAPED).mean() > 0.5 and np.isfinite(np.stack([base["rgb"][k] for k in "xyz"], 1)).all()
-    for opts in ({"nif_split": 32}, {"nif_split": 8}, {"nif_split": 24}, {"nif_first_test": 0}, {"nif_split": 24, "nif_first_test": 0}, {"nif_overlap": 0}, {"nif_overlap": 1},
+    for opts in ({"nif_split": 32}, {"nif_split": 8}, {"nif_split": 24}, {"nif_first_test": 1}, {"nif_split": 24, "nif_first_test": 1}, {"nif_overlap": 0}, {"nif_overlap": 1},
                  {"nif_spl": 16}, {"nif_spl": 64}):
         assert_streams_identical(render(**opts), base, f"NIF render with {opts}")
 

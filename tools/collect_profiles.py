@@ -5,7 +5,7 @@ first argument, default r03):
   r02_<set>_pmc.csv              one row per counter of the set's dominant kernel (mean over the timed launches)
   r02_pmc_summary.json           what bench.py quotes as offline-measured (HBM bytes per launch, VALU figures)
   r02_bench.json                 the un-profiled bench line of the same build
-  r02_config5.json               config 5 at 1440^2 x 4000 spp on one GPU + the kernel shares of a profiled 512-spp run"""
+  r02_config5.json               config 5 at 1440^2 x 4000 spp on one GPU + the kernel shares of a profiled 1024-spp run"""
 import csv, glob, json, shutil, subprocess, sys
 from pathlib import Path
 R = Path(__file__).resolve().parent.parent
@@ -139,11 +139,11 @@ tot = sum(float(r["TotalDurationNs"]) for r in st) or 1.0
 shares = {r["Name"].split("(")[0][:60]: round(float(r["TotalDurationNs"]) / tot, 4) for r in st if float(r["TotalDurationNs"]) / tot > 0.002}
 mlp = next((r for r in st if "nif_asm_kernel" in r["Name"] or "nif_mlp_kernel" in r["Name"]), None)
 c5["ms_per_frame_4000spp"] = c5["ms_per_sample"] * 4000
-c5["kernel_time_shares_512spp_profiled"] = shares
+c5["kernel_time_shares_1024spp_profiled"] = shares
 if mlp:
     c5["nif_mlp_share"] = round(float(mlp["TotalDurationNs"]) / tot, 4)
 c5["k3_mfma_frac_of_2.5PF"] = bench["nif"]["roofline"]["frac"]
-c5["note"] = f"tools/bench_config5.py 4000 on one MI355X (device-resident stream, synthetic NIF weights of the reference's shape); shares from rocprofv3 --kernel-trace --stats of the same tool at 512 spp (profiles/{TAG}_c5_kernel_stats.csv)"
+c5["note"] = f"tools/bench_config5.py 4000 on one MI355X (device-resident stream, synthetic NIF weights of the reference's shape); shares from rocprofv3 --kernel-trace --stats of the same tool at 1024 spp (two launches of 512 samples) (profiles/{TAG}_c5_kernel_stats.csv)"
 (DST / f"{TAG}_config5.json").write_text(json.dumps(c5, indent=1))
 report.append(f"c5: {c5['ms_per_sample']:.3f} ms per sample, {c5['ms_per_frame_4000spp'] / 1e3:.2f} s per 4000-spp frame; MLP share {c5.get('nif_mlp_share')}")
 if (SRC / "variants.txt").exists():

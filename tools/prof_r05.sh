@@ -44,7 +44,7 @@ done
 $R/tools/prof_nif.sh gpurun_out/prof_r05/nif_w6 --shape w6 --reps 20 > $OUT/nif_w6.log 2>&1 || echo "nif w6 failed"
 # config 5 at its real size on one GPU: monkey + NIF, 1440^2 x 4000 spp, un-profiled for the wall time and with --stats for the kernel shares
 python3 $R/tools/bench_config5.py 4000 > $OUT/c5_full.json 2> $OUT/c5_full.err || echo "config 5 run failed"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5/stats -o st -- python3 $R/tools/bench_config5.py 512 > $OUT/c5_stats.log 2>&1 || echo "c5 stats failed"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5/stats -o st -- python3 $R/tools/bench_config5.py 1024 > $OUT/c5_stats.log 2>&1 || echo "c5 stats failed"
 # the node-gather microbenchmark (the measured roof K1w's record quotes): the table, and PMC passes at saturation
 python3 $R/tools/gather_probe.py --out $OUT/gather_probe.json > $OUT/gather_probe.txt 2>&1 || echo "gather probe failed"
 for cfg in "tree35 0,1,35,6" "uni35 0,0,35,6" "tree64 0,1,64,6" "lds35 1,1,35,6"; do
