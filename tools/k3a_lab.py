@@ -87,7 +87,7 @@ def run(rounds, reps, out, cus=()):
     for k, ts in times.items():
         args = (OUT / f"lib_{k}.args").read_text() if (OUT / f"lib_{k}.args").exists() else ""
         same = None
-        if k in hs and "--ko" not in args and "-D" not in args:
+        if k in hs and "--ko" not in args and "MI_K3A_KO" not in args:
             lib, h = hs[k]
             got = np.zeros((n, 3), np.float32); lib.lab_result(h, got.ctypes.data)
             if ref is None: ref = got
