@@ -177,6 +177,11 @@ int mi_get_phase_stats(mi_scene* scene, uint64_t stats[12]);
 /* Scheduler bookkeeping of the path-pool kernel (kernel 3, instrumented build only): {loop iterations, refill turns,
  * lanes refilled, idle iterations, lost ring claims, traversal bursts, lanes walking at burst start, cycles in refill}. */
 int mi_get_pool_stats(mi_scene* scene, uint64_t stats[8]);
+/* Measurement only: enqueues, on a stream of the scene's own, ONE wave that samples the work counter of `hip_stream`'s persistent
+ * launches n times, period_ticks (100-MHz ticks) apart, into d_samples (device memory, 2 n words: {s_memrealtime, counter}). Call it
+ * right before mi_render_device on `hip_stream`; read the samples after a device synchronise (tools/launch_progress.py: the rate at which
+ * a launch hands its work units out over its life). No reference counterpart. */
+int mi_debug_launch_progress(mi_scene* scene, void* hip_stream, uint64_t* d_samples, uint32_t n, uint32_t period_ticks);
 /* Diagnostics of NIF renders (only filled while the scene option "nif_timing" is 1): HIP events bracket every launch of
  * the MLP kernel on the render's stream. out[0] = milliseconds spent in MLP launches since the last call, out[1] = number
  * of launches. Synchronises the device and clears the record. tools/bench_config5.py reports the MLP's share of a frame

@@ -208,6 +208,7 @@ def device_lib(variants: bool = False) -> C.CDLL:
         lib.mi_group_gathered_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_uint32]
         lib.mi_group_reset_counters.argtypes = [C.c_void_p]
         lib.mi_get_pool_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        lib.mi_debug_launch_progress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
         lib.mi_scene_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         lib.mi_get_nif_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         lib.mi_get_nif_clock.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
@@ -479,6 +480,11 @@ class IpuScene:
         c = (C.c_uint64 * 8)()
         self._check(self._lib.mi_get_pool_stats(self._h, c))
         return dict(zip(("loops", "refill_turns", "refill_lanes", "idle", "lost_claims", "bursts", "burst_lanes", "refill_cycles"), [int(x) for x in c]))
+
+    def launch_progress(self, d_samples: int, n: int, period_ticks: int, stream: int = 0) -> None:
+        """mi_debug_launch_progress: one wave samples the work counter of `stream`'s persistent launches n times, period_ticks
+        (100-MHz ticks) apart, into 2 n uint64 of device memory at d_samples. Call right before run_device on `stream`."""
+        self._check(self._lib.mi_debug_launch_progress(self._h, C.c_void_p(stream), C.c_void_p(d_samples), n, period_ticks))
 
     def nif_timing(self) -> dict:
         """Milliseconds in MLP launches (and their number) since the last call; needs set_option("nif_timing", 1)."""

@@ -329,6 +329,7 @@ struct mi_scene {
     hipEvent_t traced = nullptr, done = nullptr; bool donePending = false;
   } nifSlots[2];
   hipStream_t nifAux = nullptr;
+  hipStream_t debugStream = nullptr;      // mi_debug_launch_progress
   // option "nif_split": the same pair of streams with compute-unit masks (the first numCUs - x units / the last x; a mask's bit i is
   // unit i / XCDs of XCD i % XCDs, so any multiple of the XCD count splits every XCD alike). splitUnits = x they were made for.
   hipStream_t nifSplitMlp = nullptr, nifSplitTrace = nullptr;
@@ -350,13 +351,13 @@ struct mi_scene {
     // stream may be gone by now. hipFree below synchronises on its own account in this runtime; correctness does not rest on it.)
     for (LaunchSlot& l : slots) if (l.lastWork) (void)hipEventSynchronize(l.lastWork);
     if (nifAux) (void)hipStreamSynchronize(nifAux);
-    for (hipStream_t q : {nifSplitMlp, nifSplitTrace}) if (q) (void)hipStreamSynchronize(q);
+    for (hipStream_t q : {nifSplitMlp, nifSplitTrace, debugStream}) if (q) (void)hipStreamSynchronize(q);
     for (void* p : allocations) (void)hipFree(p);
     if (d_rng) (void)hipFree(d_rng);
     freeNifSlots();
     for (NifSlots& q : nifSlots) { if (q.count) (void)hipFree(q.count); if (q.traced) (void)hipEventDestroy(q.traced); if (q.done) (void)hipEventDestroy(q.done); }
     if (nifAux) (void)hipStreamDestroy(nifAux);
-    for (hipStream_t q : {nifSplitMlp, nifSplitTrace}) if (q) (void)hipStreamDestroy(q);
+    for (hipStream_t q : {nifSplitMlp, nifSplitTrace, debugStream}) if (q) (void)hipStreamDestroy(q);
     if (splitFirst) (void)hipEventDestroy(splitFirst);
     if (d_segTotal) (void)hipFree(d_segTotal);
     for (LaunchSlot& l : slots) { if (l.lastWork) (void)hipEventDestroy(l.lastWork); if (l.d_workCounter) (void)hipFree(l.d_workCounter); if (l.d_segPart) (void)hipFree(l.d_segPart); if (l.d_coords) (void)hipFree(l.d_coords); if (l.d_poolScratch) (void)hipFree(l.d_poolScratch); }
@@ -1102,6 +1103,34 @@ int mi_get_pool_stats(mi_scene* scene, uint64_t stats[8]) {      // (zeros in a 
     unsigned long long h[32];
     HIP_CHECK(hipMemcpy(h, scene->d_counters, sizeof h, hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; ++i) stats[i] = h[16 + i];
+  });
+}
+
+// One wave that samples the work counter of `hip_stream`'s persistent launches `n` times, `period_ticks` (100-MHz ticks) apart, into
+// d_samples as pairs {s_memrealtime, counter}: how fast a launch hands its work units out over its life - the ramp at its start, the
+// moment the queue runs empty, the drain behind it (tools/launch_progress.py). It runs on a stream of the scene's own beside the launch it
+// watches (K1w leaves every SIMD room for it), ends after n samples whatever happens, and changes nothing it looks at.
+__global__ void __launch_bounds__(64) launch_progress_kernel(const uint32_t* counter, unsigned long long* samples, uint32_t n, uint32_t periodTicks) {
+  if (threadIdx.x != 0) return;
+  unsigned long long next = __builtin_amdgcn_s_memrealtime();
+  for (uint32_t i = 0; i < n; ++i) {
+    unsigned long long now;
+    uint32_t spins = 0;
+    do { __builtin_amdgcn_s_sleep(32); now = __builtin_amdgcn_s_memrealtime(); } while (now < next && ++spins < (1u << 22));
+    samples[2 * i] = now;
+    samples[2 * i + 1] = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    next += periodTicks;
+  }
+}
+
+int mi_debug_launch_progress(mi_scene* scene, void* hip_stream, uint64_t* d_samples, uint32_t n, uint32_t period_ticks) {
+  if (!scene || !d_samples || n == 0 || n > (1u << 20) || period_ticks == 0 || period_ticks > 100000000u) { g_err = "mi_debug_launch_progress: bad argument"; return MI_ERR_INVALID_ARG; }
+  return guarded([&] {
+    HIP_CHECK(hipSetDevice(scene->device));
+    LaunchSlot& slot = scene->slotFor((hipStream_t)hip_stream);
+    if (!scene->debugStream) HIP_CHECK(hipStreamCreateWithFlags(&scene->debugStream, hipStreamNonBlocking));
+    hipLaunchKernelGGL(launch_progress_kernel, dim3(1), dim3(64), 0, scene->debugStream, slot.d_workCounter, reinterpret_cast<unsigned long long*>(d_samples), n, period_ticks);
+    HIP_CHECK(hipGetLastError());
   });
 }
 
