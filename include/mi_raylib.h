@@ -235,7 +235,7 @@ int mi_scene_set_ray_batch(mi_scene* scene, size_t rays_per_batch);
  *   "tiles"         0 | 1           walk row-structured streams in 8x8 pixel tiles
  *   "seg_budget_kb" N >= 1          partial-sum buffer budget per launch
  *   "nif_spl"       0..1024         NIF samples per launch, rounded up to whole segments (0 = default: 512, memory permitting - 48 B of
- *                                   slots per sample and pixel; a launch short of work units ends in a long drain: 128 per launch cost
+ *                                   slots per sample and pixel; a launch is never shorter than its longest work unit: 128 samples per launch cost
  *                                   config 5 5 % of its frame)
  *   "nif_shape"     auto | a8 | b4 | w6 | t6 | t4    which NIF MLP kernel runs (b4 = K3a's dataflow with four waves of 64 rays: 3 % slower): auto (default) = a8 where its generated body covers the network
  *                                   (the reference's 6 x 320 shape), w6 otherwise; a8 = K3a, the hand-scheduled register-resident kernel

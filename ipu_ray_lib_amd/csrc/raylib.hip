@@ -93,8 +93,8 @@ const float* hostSinTable() {
 // stand when the scene is created (read once, into the scene) and by mi_scene_set_option afterwards. Nothing here is
 // process-global: creating or tuning scene B never changes what scene A launches.
 // Samples a NIF render traces per launch (option nif_spl; the default, memory permitting - ensureScratch). A launch of the persistent
-// kernel ends in a drain - lanes whose 64-sample work atom is the last the queue had wait for the longest one of their wave - and a
-// 1440^2 launch of 128 samples is only ten atoms per lane: config 5's trace launches took 22 ms per 128 samples that way, 15 with 256
+// kernel cannot be shorter than its longest work unit - 64 samples of one pixel, ~14 ms for a pixel on config 5's mesh - and a
+// 1440^2 launch of 128 samples is only ten units per lane: config 5's trace launches took 22 ms per 128 samples that way, 15 with 256
 // per launch, 11 with 512 and no less with 768 or 1 024 (profiles/r05_config5_launch_ab.txt); 512 samples are 48 B x 512 per pixel, 51 GB
 // of a 1440^2 frame's 288.
 constexpr uint32_t kNifSplDefault = 512, kNifSplMax = 1024;
