@@ -354,7 +354,7 @@ def generate(kinds, relu, dma_at=(1, 6, 11, 16, 21), epi_start=4, ko=0, prio=0, 
                 bias_read(l + 1, 0)
         # LDS-DMA pieces of the next chunk at fixed places of this chunk
         cnt_c = net.chunks[c][1]
-        places = (dma_at if NW == 8 else tuple(range(1, 31, 3))) if cnt_c == CH else (tuple(range(1, 2 * 5, 2)) if NW == 8 else tuple(range(10)))
+        places = (dma_at if (NW == 8 or len(dma_at) == 10) else tuple(range(1, 31, 3))) if cnt_c == CH else (tuple(range(1, 2 * 5, 2)) if NW == 8 else tuple(range(10)))
         if stagger and cnt_c == CH:
             # the two waves of a SIMD issue their pieces `stagger` fragments apart: an LDS-DMA instruction holds its wave for tens of
             # cycles, and side by side both waves' MFMAs stop for them
@@ -407,7 +407,7 @@ def main():
     global NW
     NW = a.waves
     relu = [c == "1" for c in (a.relu or "1" * (len(a.kinds) - 1) + "0")]
-    net, lines = generate(a.kinds, relu, tuple(int(x) for x in a.dma_at.split(",")), a.epi_start, a.ko, a.prio, a.stagger, a.young_prio, a.mt)
+    net, lines = generate(a.kinds, relu, tuple(int(x) for x in a.dma_at.replace(":", ",").split(",")), a.epi_start, a.ko, a.prio, a.stagger, a.young_prio, a.mt)
     T = a.tag
     with open(a.out, "w") as f:
         f.write(f"// generated by nif_asm_gen.py --kinds {a.kinds} --relu {''.join('1' if r else '0' for r in relu)} --waves {NW} --mt {a.mt}: do not edit\n")
