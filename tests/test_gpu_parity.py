@@ -585,6 +585,40 @@ def test_nif_render_schedule_options_leave_every_byte_alone():
         assert_streams_identical(render(**opts), base, f"NIF render with {opts}")
 
 
+def test_launch_progress_probe_watches_without_touching(scenes):
+    """mi_debug_launch_progress: one wave beside a persistent launch samples its work counter. The render it watches must give the
+    oracle's bytes as always, the samples' clock must run forward, and the counter must be seen rising to (at least) the launch's
+    number of work units - 4 per pixel at 16 spp - and never falling within the launch."""
+    import torch
+    s = scenes["box"]
+    with _desc_restored(s.desc) as d:
+        d.set_image(256, 192); d.samples_per_pixel = 16; d.path_trace = 1
+        dev = irl.IpuScene(d)
+        host = s.init_ray_stream(); want = host.copy(); n = host.size
+        rays = torch.from_numpy(host.view(np.uint8).reshape(n, irl.TRACE_RESULT.itemsize).copy()).cuda()
+        st = torch.cuda.current_stream().cuda_stream
+        dev.run_device(rays.data_ptr(), n, irl.MODE_PATH_TRACE, st)     # (leaves the counter at a first launch's final value)
+        torch.cuda.synchronize()
+        samples = 4000
+        buf = torch.zeros(2 * samples, dtype=torch.int64, device="cuda")
+        dev.launch_progress(buf.data_ptr(), samples, 100, st)          # every microsecond, 4 ms long
+        dev.run_device(rays.data_ptr(), n, irl.MODE_PATH_TRACE, st)
+        torch.cuda.synchronize()
+        a = buf.cpu().numpy().reshape(-1, 2)
+        t, c = a[:, 0], a[:, 1]
+        assert (np.diff(t) > 0).all()
+        items = n * 4
+        falls = np.nonzero(np.diff(c) < 0)[0]
+        assert falls.size == 1, falls                                  # the launch's reset of the counter, seen once
+        after = c[falls[0] + 1:]
+        assert (np.diff(after) >= 0).all() and after[0] < items
+        assert items <= after[-1] < items + (1 << 22) and c[0] == after[-1]      # (it overshoots by at most a chunk per wave; both launches end alike)
+        got = np.frombuffer(rays.cpu().numpy().tobytes(), dtype=irl.TRACE_RESULT)
+        ol.path_trace_pixel_rng(d, want, 16); ol.path_trace_pixel_rng(d, want, 16)      # (two renders accumulated onto the stream's rgb)
+        assert_streams_identical(got, want, "render watched by the progress probe")
+        dev.close()
+
+
 @pytest.mark.parametrize("shape", ["w6", "a8", "b4", "r8"])
 def test_nif_render_with_every_mlp_kernel_skips_the_lists_holes(shape):
     """The trace kernel reserves room in the escaped-slot list 2 048 entries at a time; what a wave leaves unused of its last
