@@ -622,7 +622,7 @@ void ensureScratch(mi_scene& S, size_t n) {
   S.scratchRays = n;
 }
 
-constexpr uint32_t kLdsBudgetBytes = 160 * 1024 - 2048 - 23 * 1024 * 4;     // 160 KiB per CU minus the static allocations (sin table, material cache, 23 cold-state words x 1024 threads)
+[[maybe_unused]] constexpr uint32_t kLdsBudgetBytes = 160 * 1024 - 2048 - 23 * 1024 * 4;     // 160 KiB per CU minus the static allocations (sin table, material cache, 23 cold-state words x 1024 threads)
 
 // Work indices are 32 bit and every wave takes them from the launch's counter in chunks of fetchChunk (64): a wave
 // that finds the counter past the end still adds its chunk, so the counter may overshoot the item count by
