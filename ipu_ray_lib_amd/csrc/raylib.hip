@@ -933,6 +933,23 @@ void launchRender(mi_scene& S, int mode, mi_trace_result* d_rays, size_t n, hipS
   HIP_CHECK(hipEventRecord(S.slotFor(stream).lastWork, stream));      // (~mi_scene waits for it)
 }
 
+// One wave that samples the work counter of `hip_stream`'s persistent launches `n` times, `period_ticks` (100-MHz ticks) apart, into
+// d_samples as pairs {s_memrealtime, counter}: how fast a launch hands its work units out over its life - the ramp at its start, the
+// moment the queue runs empty, the drain behind it (tools/launch_progress.py). It runs on a stream of the scene's own beside the launch it
+// watches (K1w leaves every SIMD room for it), ends after n samples whatever happens, and changes nothing it looks at.
+__global__ void __launch_bounds__(64) launch_progress_kernel(const uint32_t* counter, unsigned long long* samples, uint32_t n, uint32_t periodTicks) {
+  if (threadIdx.x != 0) return;
+  unsigned long long next = __builtin_amdgcn_s_memrealtime();
+  for (uint32_t i = 0; i < n; ++i) {
+    unsigned long long now;
+    uint32_t spins = 0;
+    do { __builtin_amdgcn_s_sleep(32); now = __builtin_amdgcn_s_memrealtime(); } while (now < next && ++spins < (1u << 22));
+    samples[2 * i] = now;
+    samples[2 * i + 1] = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    next += periodTicks;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1104,23 +1121,6 @@ int mi_get_pool_stats(mi_scene* scene, uint64_t stats[8]) {      // (zeros in a 
     HIP_CHECK(hipMemcpy(h, scene->d_counters, sizeof h, hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; ++i) stats[i] = h[16 + i];
   });
-}
-
-// One wave that samples the work counter of `hip_stream`'s persistent launches `n` times, `period_ticks` (100-MHz ticks) apart, into
-// d_samples as pairs {s_memrealtime, counter}: how fast a launch hands its work units out over its life - the ramp at its start, the
-// moment the queue runs empty, the drain behind it (tools/launch_progress.py). It runs on a stream of the scene's own beside the launch it
-// watches (K1w leaves every SIMD room for it), ends after n samples whatever happens, and changes nothing it looks at.
-__global__ void __launch_bounds__(64) launch_progress_kernel(const uint32_t* counter, unsigned long long* samples, uint32_t n, uint32_t periodTicks) {
-  if (threadIdx.x != 0) return;
-  unsigned long long next = __builtin_amdgcn_s_memrealtime();
-  for (uint32_t i = 0; i < n; ++i) {
-    unsigned long long now;
-    uint32_t spins = 0;
-    do { __builtin_amdgcn_s_sleep(32); now = __builtin_amdgcn_s_memrealtime(); } while (now < next && ++spins < (1u << 22));
-    samples[2 * i] = now;
-    samples[2 * i + 1] = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    next += periodTicks;
-  }
 }
 
 int mi_debug_launch_progress(mi_scene* scene, void* hip_stream, uint64_t* d_samples, uint32_t n, uint32_t period_ticks) {
