@@ -494,6 +494,41 @@ def test_nif_mlp_against_oracle(scenes, shape):
     dev.close()
 
 
+@pytest.mark.parametrize("shape,cus", [("a8", 0), ("a8", 3), ("b4", 0), ("b4", 7)])
+def test_k3a_pass_counters_return_to_zero(scenes, shape, cus):
+    """K3a / K3b draw their passes from a counter that must be back at zero when the launch ends (atomicInc wrapping at the launch's
+    number of draws; 64 counters taken in turn). 150 launches of one scene with ray counts from 1 to 70 000 - fewer passes than
+    workgroups, exactly as many, more - into a NaN-filled buffer: every launch must fill exactly its rows, with the bits the first,
+    largest launch gave those rows (a row's result depends on the row alone). A counter left off zero would make a later launch skip
+    or repeat passes."""
+    import torch
+    rng = np.random.default_rng(17)
+    ks, bs, relu = _nif_weights(rng)
+    mean = np.array([-2.3514461517333984, -2.2660605907440186, -1.9648972749710083], np.float32) - np.float32(1e-8)
+    dev = irl.IpuScene(scenes["spheres"].desc).set_option("nif_shape", shape)
+    if cus:
+        dev.set_option("cus", cus)
+    dev.setNif(ks, bs, relu, 12, 3.4299468994140625, mean, True)
+    nmax = 70000
+    u = torch.from_numpy(rng.random(nmax).astype(np.float32)).cuda(); v = torch.from_numpy(rng.random(nmax).astype(np.float32)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    ref = torch.full((nmax, 3), float("nan"), device="cuda")
+    dev.nif_infer_device(u.data_ptr(), v.data_ptr(), ref.data_ptr(), nmax, st)
+    torch.cuda.synchronize()
+    assert torch.isfinite(ref).all()
+    grid = cus if cus else torch.cuda.get_device_properties(0).multi_processor_count
+    sizes = [1, 255, 256, 257, 256 * grid - 1, 256 * grid, 256 * grid + 1, nmax] + [int(x) for x in rng.integers(1, nmax, 142)]
+    out = torch.empty((nmax, 3), device="cuda")
+    for n in sizes:
+        n = min(n, nmax)
+        out.fill_(float("nan"))
+        dev.nif_infer_device(u.data_ptr(), v.data_ptr(), out.data_ptr(), n, st)
+        torch.cuda.synchronize()
+        assert torch.equal(out[:n].view(torch.int32), ref[:n].view(torch.int32)), n
+        assert torch.isnan(out[n:]).all(), n
+    dev.close()
+
+
 @pytest.mark.parametrize("hidden,layers", [(32, 2), (64, 3), (96, 2), (128, 6), (160, 5), (224, 3), (256, 4), (320, 3), (352, 3), (384, 2)])
 @pytest.mark.parametrize("kernel", ["w6", "r8"])
 def test_nif_mlp_shapes_against_oracle(scenes, hidden, layers, kernel):
