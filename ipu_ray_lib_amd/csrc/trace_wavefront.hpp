@@ -216,9 +216,11 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 256 && WAVES_PER_SIMD > 4) ? 
   // their environment coordinates (PreProcessEscapedRays, codelets/TraceCodelets.cpp:321-358, same arithmetic as
   // escaped_uv_kernel) and throughput. The wave takes room in the list kEnvChunk entries at a time: one atomic on the ONE
   // counter every wave of the launch shares per chunk, not per turn - in an open scene nearly every SHADE turn has an escape,
-  // and the waves queued behind that address (profiles/r04_nif_trace_ab.txt). What a wave has left of its last chunk when it
-  // runs out of work is padded with a slot it wrote before: the MLP evaluates that ray once more into the same slot, which
-  // changes nothing (each row's result depends on the row alone).
+  // and the waves queued behind that address (profiles/r04_nif_trace_ab.txt; the atomics execute at the memory side, ~14 ns apart:
+  // with 256 entries per atomic they were still 18 ms of a 21-ms launch, hence 2 048 - profiles/r05_config5_launch_ab.txt). What a
+  // wave has left of its last chunk when it runs out of work: the 256-entry block it stands in is padded with a slot it wrote before
+  // (the MLP evaluates that ray once more into the same slot, which changes nothing - a row's result depends on the row alone), the
+  // whole blocks behind it are marked as holes no MLP kernel evaluates (kEnvHole).
   uint32_t envNext = 0, envEnd = 0, envFill = 0;      // wave-uniform
   auto pushEscaped = [&](bool envRay, uint32_t envSlot) {
     const unsigned long long mE = __ballot(envRay);
